@@ -1,0 +1,88 @@
+"""ctypes binding of csrc/libdsr_hip.so (C ABI: include/dsr_hip.h).
+
+The HIP library is the product: there is NO fallback.  If the shared object is missing
+or a symbol cannot be resolved this module raises, and every op that reaches `lib()` on a
+machine without a GPU fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libdsr_hip.so")
+
+BF16, F16 = 0, 1
+ACT_NONE, ACT_LEAKY, ACT_PRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = range(6)
+PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = range(3)
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("dtype", "N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "pad_mode")]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("act", C.c_int), ("slope", C.c_float), ("prelu", C.c_void_p), ("bias", C.c_void_p),
+                ("stats_partial", C.c_void_p), ("pixel_shuffle", C.c_int), ("out_nchw_f32", C.c_void_p)]
+
+
+_P, _I, _F, _Z, _LL = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
+_DESC = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); every symbol declared in include/dsr_hip.h
+SIGNATURES = {
+    "dsr_last_error": (C.c_char_p, []),
+    "dsr_abi_version": (_I, []),
+    "dsr_conv_out_size": (_I, [_DESC, C.POINTER(_I), C.POINTER(_I)]),
+    "dsr_conv_stats_rows": (_I, [_DESC]),
+    "dsr_conv_packed_elems": (_Z, [_DESC, _I]),
+    "dsr_conv_pack_weight": (_I, [_DESC, _P, _P, _P, _P]),
+    "dsr_conv_fwd": (_I, [_DESC, _P, _P, C.POINTER(Epilogue), _P, _P]),
+    "dsr_conv_dgrad_workspace": (_Z, [_DESC]),
+    "dsr_conv_dgrad": (_I, [_DESC, _P, _P, _P, _P, _Z, _P]),
+    "dsr_conv_wgrad_workspace": (_Z, [_DESC]),
+    "dsr_conv_wgrad": (_I, [_DESC, _P, _P, _P, _P, _Z, _P]),
+    "dsr_pw_nchw_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dsr_pw_nhwc_to_nchw": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dsr_pw_pack_weight": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dsr_pw_sum_rows": (_I, [_P, _I, _I, _I, _F, _P, _I, _P]),
+    "dsr_pw_bn_finalize": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P]),
+    "dsr_pw_bn_eval_affine": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P]),
+    "dsr_pw_reduce_blocks": (_I, [_Z, C.POINTER(_I)]),
+    "dsr_pw_channel_stats": (_I, [_I, _P, _Z, _I, _I, _I, _P, _P]),
+    "dsr_pw_bn_act_fwd": (_I, [_I, _P, _P, _P, _P, _P, _Z, _I, _I, _F, _P, _P]),
+    "dsr_pw_bn_act_bwd_reduce": (_I, [_I, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "dsr_pw_bn_bwd_finalize": (_I, [_P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
+    "dsr_pw_bn_act_bwd_apply": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _F, _P, _I, _P]),
+    "dsr_pw_act_bwd": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P]),
+    "dsr_pw_act_bwd_nchw": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dsr_pw_colsum": (_I, [_I, _P, _Z, _I, _I, _I, _P, _P]),
+    "dsr_pw_add": (_I, [_I, _P, _P, _P, _Z, _P]),
+    "dsr_pw_diff_loss": (_I, [_P, _P, _P, _Z, _I, _P, _I, _P]),
+    "dsr_pw_bce_const": (_I, [_P, _I, _F, _P, _P, _I, _P]),
+    "dsr_pw_adam": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P, _P]),
+    "dsr_pw_incr": (_I, [_P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it was not built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(f"{SO_PATH} is missing: the HIP extension is the only implementation of this "
+                               "package (no CPU fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+        h = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("dsr_hip: " + lib().dsr_last_error().decode())
+    return rc

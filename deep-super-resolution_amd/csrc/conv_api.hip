@@ -1,0 +1,307 @@
+// C-ABI entry points for convolution forward / input-grad / weight-grad (include/dsr_hip.h).
+// Host code only: turns an nn.Conv2d-style descriptor into the tap table + grid mapping the
+// gather-GEMM kernel (conv_gemm.hip) consumes.  No allocation, no synchronisation: capturable.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dsr_hip.h"
+#include "dsr_common.h"
+#include "dsr_kernels.h"
+
+static thread_local char g_err[512] = "";
+
+int dsr_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+int dsr_launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dsr_fail(DSR_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return DSR_OK;
+}
+extern "C" const char* dsr_last_error(void) { return g_err; }
+extern "C" int dsr_abi_version(void) { return 1; }
+
+static inline int r8(int c) { return (c + 7) & ~7; }
+
+static int check_desc(const dsr_conv_desc* d) {
+  if (!d) return dsr_fail(DSR_E_ARG, "conv: null descriptor");
+  if (d->dtype != DSR_BF16 && d->dtype != DSR_F16) return dsr_fail(DSR_E_ARG, "conv: dtype %d", d->dtype);
+  if (d->N < 1 || d->H < 1 || d->W < 1 || d->Cin < 1 || d->Cout < 1) return dsr_fail(DSR_E_ARG, "conv: empty shape");
+  if (d->KH < 1 || d->KW < 1 || d->stride < 1 || d->pad < 0) return dsr_fail(DSR_E_ARG, "conv: bad kernel/stride/pad");
+  if (d->KH * d->KW > DSR_MAX_TAPS) return dsr_fail(DSR_E_UNSUPPORTED, "conv: %dx%d taps > %d", d->KH, d->KW, DSR_MAX_TAPS);
+  if (d->pad_mode < 0 || d->pad_mode > 2) return dsr_fail(DSR_E_ARG, "conv: pad_mode %d", d->pad_mode);
+  if (d->pad_mode == DSR_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W))
+    return dsr_fail(DSR_E_ARG, "conv: reflect pad %d >= input size", d->pad);   // torch raises the same
+  if (d->KH > 127 || d->KW > 127) return dsr_fail(DSR_E_UNSUPPORTED, "conv: kernel too large");
+  int OH = (d->H + 2 * d->pad - d->KH) / d->stride + 1, OW = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  if (OH < 1 || OW < 1) return dsr_fail(DSR_E_ARG, "conv: output would be empty");
+  if ((long long)d->N * d->H * d->W >= (1ll << 31) / 64 * 8) return dsr_fail(DSR_E_UNSUPPORTED, "conv: tensor too large");
+  return DSR_OK;
+}
+
+extern "C" int dsr_conv_out_size(const dsr_conv_desc* d, int* OH, int* OW) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  *OH = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+  *OW = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  return DSR_OK;
+}
+
+extern "C" int dsr_conv_stats_rows(const dsr_conv_desc* d) {
+  int OH, OW;
+  if (dsr_conv_out_size(d, &OH, &OW)) return -1;
+  long long M = (long long)d->N * OH * OW;
+  return (int)((M + 127) / 128);
+}
+
+extern "C" size_t dsr_conv_packed_elems(const dsr_conv_desc* d, int dgrad) {
+  size_t T = (size_t)d->KH * d->KW;
+  return dgrad ? T * r8(d->Cin) * r8(d->Cout) : T * r8(d->Cout) * r8(d->Cin);
+}
+
+extern "C" int dsr_conv_pack_weight(const dsr_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad,
+                                    dsr_stream_t s) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!w || !w_fwd) return dsr_fail(DSR_E_ARG, "pack: null pointer");
+  return dsr_pw_pack_weight(d->dtype, w, w_fwd, w_dgrad, d->Cout, d->Cin, d->KH * d->KW, r8(d->Cout), r8(d->Cin),
+                            r8(d->Cin), r8(d->Cout), s);
+}
+
+static inline int pack_tap(int dy, int dx, int widx) { return (dy & 0xff) | ((dx & 0xff) << 8) | (widx << 16); }
+
+static void finish_args(ConvGemmArgs& a) {
+  a.CU = a.CinP / 8;
+  a.U = a.ntaps * a.CU;
+  a.ksteps = (a.U + 7) / 8;
+  a.fd_ghw = fd_make((unsigned)(a.GH * a.GW));
+  a.fd_gw = fd_make((unsigned)a.GW);
+  a.fd_cu = fd_make((unsigned)a.CU);
+}
+
+extern "C" int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w_fwd, const dsr_epilogue* e, void* y,
+                            dsr_stream_t s) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!x || !w_fwd || !e) return dsr_fail(DSR_E_ARG, "conv_fwd: null pointer");
+  if (!y && !e->out_nchw_f32) return dsr_fail(DSR_E_ARG, "conv_fwd: no output");
+  int OH, OW;
+  dsr_conv_out_size(d, &OH, &OW);
+  ConvGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x;
+  a.w = w_fwd;
+  a.y = y;
+  a.out_f32 = e->out_nchw_f32;
+  a.bias = e->bias;
+  a.prelu = e->prelu;
+  a.stats = e->stats_partial;
+  a.GH = OH;
+  a.GW = OW;
+  a.M = d->N * OH * OW;
+  a.IH = d->H;
+  a.IW = d->W;
+  a.CinP = r8(d->Cin);
+  a.NB = r8(d->Cout);
+  a.cout = d->Cout;
+  a.stats_stride = r8(d->Cout);
+  a.isy = a.isx = d->stride;
+  a.osy = a.osx = 1;
+  a.pad_mode = d->pad_mode;
+  a.act = e->act;
+  a.slope = e->slope;
+  a.flags = (e->bias ? DSR_F_BIAS : 0) | (e->stats_partial ? DSR_F_STATS : 0) |
+            (e->out_nchw_f32 ? DSR_F_OUT_NCHW_F32 : 0) | ((e->act == DSR_ACT_PRELU && e->prelu) ? DSR_F_PRELU_PTR : 0);
+  if (e->act == DSR_ACT_PRELU && !e->prelu) return dsr_fail(DSR_E_ARG, "conv_fwd: PReLU needs its weight pointer");
+  if (e->pixel_shuffle) {
+    if (d->Cout % 4 || d->Cout < 32 || e->out_nchw_f32 || e->stats_partial)
+      return dsr_fail(DSR_E_UNSUPPORTED, "conv_fwd: pixel-shuffle epilogue needs Cout %% 4 == 0, Cout >= 32, 16-bit output");
+    a.flags |= DSR_F_PIXSHUF;
+    a.OH = 2 * OH;
+    a.OW = 2 * OW;
+    a.CoutP = r8(d->Cout / 4);
+  } else {
+    a.OH = OH;
+    a.OW = OW;
+    a.CoutP = r8(d->Cout);
+  }
+  a.ntaps = d->KH * d->KW;
+  for (int kh = 0; kh < d->KH; ++kh)
+    for (int kw = 0; kw < d->KW; ++kw) a.taps[kh * d->KW + kw] = pack_tap(kh - d->pad, kw - d->pad, kh * d->KW + kw);
+  finish_args(a);
+  dsr_launch_conv_gemm(a, d->dtype, s);
+  return dsr_launch_status("dsr_conv_fwd");
+}
+
+// ---- reflect-padding adjoint: dx[i][j] = sum of dxp over the padded coordinates that mirror onto (i,j)
+template <int DT>
+__global__ void reflect_fold_kernel(const unsigned short* __restrict__ dxp, unsigned short* __restrict__ dx, int N,
+                                    int H, int W, int Cp, int p) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cpr = Cp / 8;
+  size_t total = (size_t)N * H * W * cpr;
+  if (idx >= total) return;
+  int ch = (int)(idx % cpr);
+  size_t pix = idx / cpr;
+  int j = (int)(pix % W);
+  int i = (int)((pix / W) % H);
+  int n = (int)(pix / ((size_t)W * H));
+  const int HP = H + 2 * p, WP = W + 2 * p;
+  int ys[3], xs[3], ny = 0, nx = 0;
+  ys[ny++] = i + p;
+  if (i >= 1 && i <= p) ys[ny++] = p - i;
+  if (i <= H - 2 && i >= H - 1 - p) ys[ny++] = 2 * (H - 1) - i + p;
+  xs[nx++] = j + p;
+  if (j >= 1 && j <= p) xs[nx++] = p - j;
+  if (j <= W - 2 && j >= W - 1 - p) xs[nx++] = 2 * (W - 1) - j + p;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int a = 0; a < ny; ++a)
+    for (int b = 0; b < nx; ++b) {
+      float f[8];
+      unpack8<DT>(*reinterpret_cast<const U4*>(dxp + ((size_t)(n * HP + ys[a]) * WP + xs[b]) * Cp + ch * 8), f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += f[k];
+    }
+  *reinterpret_cast<U4*>(dx + pix * Cp + ch * 8) = pack8<DT>(acc);
+}
+
+extern "C" size_t dsr_conv_dgrad_workspace(const dsr_conv_desc* d) {
+  if (d->pad_mode == DSR_PAD_ZERO || d->pad == 0) return 0;
+  return (size_t)d->N * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * r8(d->Cin) * 2;
+}
+
+extern "C" int dsr_conv_dgrad(const dsr_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* workspace,
+                              size_t ws_bytes, dsr_stream_t s) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!dy || !w_dgrad || !dx) return dsr_fail(DSR_E_ARG, "conv_dgrad: null pointer");
+  if (d->pad_mode == DSR_PAD_REPLICATE && d->pad > 0)
+    return dsr_fail(DSR_E_UNSUPPORTED, "conv_dgrad: replicate padding has no consumer on the hot path");
+  int OH, OW;
+  dsr_conv_out_size(d, &OH, &OW);
+  const bool folded = d->pad_mode == DSR_PAD_REFLECT && d->pad > 0;
+  // with reflect padding the gradient is first taken w.r.t. the PADDED input (pad = 0 problem), then folded
+  const int H = folded ? d->H + 2 * d->pad : d->H;
+  const int W = folded ? d->W + 2 * d->pad : d->W;
+  const int pad = folded ? 0 : d->pad;
+  void* target = dx;
+  if (folded) {
+    size_t need = dsr_conv_dgrad_workspace(d);
+    if (!workspace || ws_bytes < need) return dsr_fail(DSR_E_WORKSPACE, "conv_dgrad: workspace %zu < %zu", ws_bytes, need);
+    target = workspace;
+  }
+  const int st = d->stride;
+  for (int ph = 0; ph < st; ++ph)
+    for (int pw = 0; pw < st; ++pw) {
+      int GH = (H - ph + st - 1) / st, GW = (W - pw + st - 1) / st;
+      if (GH <= 0 || GW <= 0) continue;
+      ConvGemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.x = dy;
+      a.w = w_dgrad;
+      a.y = target;
+      a.GH = GH;
+      a.GW = GW;
+      a.M = d->N * GH * GW;
+      a.IH = OH;
+      a.IW = OW;
+      a.CinP = r8(d->Cout);
+      a.NB = r8(d->Cin);
+      a.cout = d->Cin;
+      a.CoutP = r8(d->Cin);
+      a.OH = H;
+      a.OW = W;
+      a.isy = a.isx = 1;
+      a.osy = a.osx = st;
+      a.ooy = ph;
+      a.oox = pw;
+      a.pad_mode = DSR_PAD_ZERO;
+      a.act = DSR_ACT_NONE;
+      int nt = 0;
+      for (int kh = 0; kh < d->KH; ++kh) {
+        if ((ph + pad - kh) % st != 0) continue;
+        for (int kw = 0; kw < d->KW; ++kw) {
+          if ((pw + pad - kw) % st != 0) continue;
+          // C '/' truncates toward zero, but (ph+pad-kh) is an exact multiple of st here
+          a.taps[nt++] = pack_tap((ph + pad - kh) / st, (pw + pad - kw) / st, kh * d->KW + kw);
+        }
+      }
+      a.ntaps = nt;
+      finish_args(a);
+      dsr_launch_conv_gemm(a, d->dtype, s);
+    }
+  if (folded) {
+    size_t total = (size_t)d->N * d->H * d->W * (r8(d->Cin) / 8);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (d->dtype == DSR_BF16)
+      hipLaunchKernelGGL((reflect_fold_kernel<DSR_DTYPE_BF16>), grid, block, 0, s, (const unsigned short*)workspace,
+                         (unsigned short*)dx, d->N, d->H, d->W, r8(d->Cin), d->pad);
+    else
+      hipLaunchKernelGGL((reflect_fold_kernel<DSR_DTYPE_F16>), grid, block, 0, s, (const unsigned short*)workspace,
+                         (unsigned short*)dx, d->N, d->H, d->W, r8(d->Cin), d->pad);
+  }
+  return dsr_launch_status("dsr_conv_dgrad");
+}
+
+static void wgrad_plan(const dsr_conv_desc* d, WgradArgs& a) {
+  int OH, OW;
+  dsr_conv_out_size(d, &OH, &OW);
+  a.M = d->N * OH * OW;
+  a.OH = OH;
+  a.OW = OW;
+  a.IH = d->H;
+  a.IW = d->W;
+  a.CinP = r8(d->Cin);
+  a.CoutP = r8(d->Cout);
+  a.stride = d->stride;
+  a.pad = d->pad;
+  a.pad_mode = d->pad_mode;
+  a.KH = d->KH;
+  a.KW = d->KW;
+  a.tiles_co = (a.CoutP + 63) / 64;
+  a.tiles_ci = (a.CinP + 63) / 64;
+  long long base = (long long)a.tiles_co * a.tiles_ci * d->KH * d->KW;
+  long long want = (1536 + base - 1) / base;   // aim at ~6 blocks per CU in flight
+  long long max_splits = (a.M + 127) / 128;
+  if (want > max_splits) want = max_splits;
+  if (want < 1) want = 1;
+  long long chunk = (a.M + want - 1) / want;
+  chunk = (chunk + 127) / 128 * 128;
+  a.chunk = (int)chunk;
+  a.splits = (int)((a.M + chunk - 1) / chunk);
+  a.fd_ohw = fd_make((unsigned)(OH * OW));
+  a.fd_ow = fd_make((unsigned)OW);
+}
+
+extern "C" size_t dsr_conv_wgrad_workspace(const dsr_conv_desc* d) {
+  if (check_desc(d)) return 0;
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  wgrad_plan(d, a);
+  return (size_t)a.splits * d->KH * d->KW * a.CoutP * a.CinP * sizeof(float);
+}
+
+extern "C" int dsr_conv_wgrad(const dsr_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace,
+                              size_t ws_bytes, dsr_stream_t s) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!x || !dy || !dw) return dsr_fail(DSR_E_ARG, "conv_wgrad: null pointer");
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  wgrad_plan(d, a);
+  size_t need = dsr_conv_wgrad_workspace(d);
+  if (!workspace || ws_bytes < need) return dsr_fail(DSR_E_WORKSPACE, "conv_wgrad: workspace %zu < %zu", ws_bytes, need);
+  a.x = x;
+  a.dy = dy;
+  a.partial = (float*)workspace;
+  dsr_launch_wgrad(a, d->dtype, s);
+  dsr_launch_wgrad_reduce(a.partial, dw, a.splits, d->KH * d->KW, d->Cout, d->Cin, a.CoutP, a.CinP, s);
+  return dsr_launch_status("dsr_conv_wgrad");
+}

@@ -1,0 +1,301 @@
+// Implicit-GEMM "gather" convolution for gfx950: out[pixel][co] = sum_{tap,ci} in[pixel(+tap)][ci] * W[tap][co][ci]
+//
+// One kernel serves conv forward, input-grad (dgrad: stride-1 directly, stride-2 as 4 output-parity
+// classes) and any k x k / stride / zero|reflect|replicate padding the reference's layers use
+// (models/GAN/generator.py:7,11,30,47,52,62; models/GAN/discriminator.py:7,25; models/DIP/utils.py:83-105),
+// because the tap list (dy, dx, weight slice) is data: see conv_api.hip for how each case fills it.
+//
+//  * NHWC 16-bit activations, channels padded to 8: one 16-byte vector = 8 channels of one pixel.
+//  * K is walked in "units" of 8 channels; a K-step is 8 units (64 k).  A-tile rows are pixels
+//    (gathered, coalesced 128 B per pixel when Cin>=64), B-tile rows are output channels.
+//  * global -> registers -> LDS (XOR-swizzled 128-B rows, conflict-free ds_read_b128), double-buffered
+//    LDS, one barrier per K-step; the next step's global loads are issued before the MFMAs of this one.
+//  * mfma_f32_16x16x32 (bf16 or f16), fp32 accumulate; 4 waves; wave tile (BM/WGM) x (BN/WGN).
+//  * epilogue: +bias, activation, per-channel sum / sum-of-squares partials for BatchNorm (from the fp32
+//    accumulators, one partial row per M-tile: deterministic, no atomics), staged through LDS so that
+//    global stores are 16-byte NHWC vectors; optional PixelShuffle(2) store
+//    (out[n,2h+i,2w+j,c] = y[n,h,w,4c+2i+j], generator.py:32,38) or fp32 NCHW store for the last layer.
+#include "dsr_common.h"
+#include "dsr_kernels.h"
+
+template <int DT, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a) {
+  static_assert(WGM * WGN == 4, "4 waves");
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  static_assert(TM >= 1 && TN >= 1, "wave tile");
+  constexpr int RA = BM / 32;
+  constexpr int RB = (BN + 31) / 32;
+  constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128;
+  constexpr int LDS_MAIN = 2 * (A_STAGE + B_STAGE);
+  constexpr int C_STRIDE = BN * 2 + 16;
+  constexpr int LDS_C = BM * C_STRIDE;
+  constexpr int LDS_BYTES = LDS_MAIN > LDS_C ? LDS_MAIN : LDS_C;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + WGM * 2 * BN * 4 + DSR_MAX_TAPS * 4];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 2 * A_STAGE;
+  float* sStat = reinterpret_cast<float*>(smem + LDS_BYTES);
+  int* sTaps = reinterpret_cast<int*>(smem + LDS_BYTES + WGM * 2 * BN * 4);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int g = lane >> 4, r16 = lane & 15;
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  for (int i = tid; i < a.ntaps; i += 256) sTaps[i] = a.taps[i];
+
+  const unsigned short* __restrict__ X = reinterpret_cast<const unsigned short*>(a.x);
+  const unsigned short* __restrict__ W = reinterpret_cast<const unsigned short*>(a.w);
+
+  // ---- loader role: unit j of the K-step, rows rb + 32*i
+  const int j = tid & 7, rb = tid >> 3;
+  int a_iy0[RA], a_ix0[RA], a_nb[RA];
+  bool a_ok[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    int m = m0 + rb + 32 * i;
+    a_ok[i] = m < a.M;
+    int mm = a_ok[i] ? m : 0;
+    int n = fd_div(a.fd_ghw, mm);
+    int rem = mm - n * (a.GH * a.GW);
+    int gy = fd_div(a.fd_gw, rem);
+    int gx = rem - gy * a.GW;
+    a_iy0[i] = gy * a.isy;
+    a_ix0[i] = gx * a.isx;
+    a_nb[i] = n * a.IH * a.IW;
+  }
+  __syncthreads();   // sTaps visible
+
+  U4 ra[RA], rbv[RB];
+  auto load_step = [&](int s) {
+    int u = s * 8 + j;
+    bool uok = u < a.U;
+    int uu = uok ? u : 0;
+    int t = fd_div(a.fd_cu, uu);
+    int c8 = uu - t * a.CU;
+    int tp = sTaps[t];
+    int dy = (int)(signed char)(tp & 0xff);
+    int dx = (int)(signed char)((tp >> 8) & 0xff);
+    int widx = (tp >> 16) & 0xffff;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      bool inb = a_ok[i] && uok;
+      int iy = pad_index(a_iy0[i] + dy, a.IH, a.pad_mode, inb);
+      int ix = pad_index(a_ix0[i] + dx, a.IW, a.pad_mode, inb);
+      size_t off = ((size_t)(a_nb[i] + iy * a.IW + ix) * a.CinP + (size_t)c8 * 8);
+      ra[i] = load16_or_zero(X, off, inb);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int row = rb + 32 * i;
+      int co = n0 + row;
+      bool ok = uok && row < BN && co < a.NB;
+      size_t off = ((size_t)(widx * a.NB + co) * a.CinP + (size_t)c8 * 8);
+      rbv[i] = load16_or_zero(W, off, ok);
+    }
+  };
+  auto store_step = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int row = rb + 32 * i;
+      *reinterpret_cast<U4*>(sA + stage * A_STAGE + row * 128 + ((j ^ (row & 7)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int row = rb + 32 * i;
+      if (row < BN) *reinterpret_cast<U4*>(sB + stage * B_STAGE + row * 128 + ((j ^ (row & 7)) << 4)) = rbv[i];
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int k = 0; k < TN; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+
+  const int sw = r16 & 7;
+  for (int s = 0; s < a.ksteps; ++s) {
+    const int cur = s & 1;
+    const bool more = (s + 1) < a.ksteps;
+    if (more) load_step(s + 1);
+    const unsigned char* pa = sA + cur * A_STAGE + (wm * WM + r16) * 128;
+    const unsigned char* pb = sB + cur * B_STAGE + (wn * WN + r16) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int slot = ((4 * kk + g) ^ sw) << 4;
+      U4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const U4*>(pa + i * 16 * 128 + slot);
+#pragma unroll
+      for (int k = 0; k < TN; ++k) fb[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int k = 0; k < TN; ++k) acc[i][k] = mfma16<DT>(fa[i], fb[k], acc[i][k]);
+    }
+    if (more) store_step(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  const float slope = (a.flags & DSR_F_PRELU_PTR) ? a.prelu[0] : a.slope;
+  const bool do_stats = (a.flags & DSR_F_STATS) != 0;
+  const bool nchw = (a.flags & DSR_F_OUT_NCHW_F32) != 0;
+  unsigned char* sC = smem;
+
+  if (nchw) {
+    // fp32 NCHW store straight from the accumulators (last layers: Cout <= 16, so this is a small tensor)
+#pragma unroll
+    for (int k = 0; k < TN; ++k) {
+      const int col = n0 + wn * WN + 16 * k + r16;
+      const bool colok = col < a.cout;
+      const float bv = ((a.flags & DSR_F_BIAS) && colok) ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * WM + 16 * i + 4 * g + r;
+          const float o = act_apply(a.act, acc[i][k][r] + bv, slope);
+          if (m < a.M && colok) {
+            int n = fd_div(a.fd_ghw, m);
+            int rem = m - n * (a.GH * a.GW);
+            int gy = fd_div(a.fd_gw, rem);
+            int gx = rem - gy * a.GW;
+            int oy = gy * a.osy + a.ooy, ox = gx * a.osx + a.oox;
+            a.out_f32[(((size_t)n * a.cout + col) * a.OH + oy) * a.OW + ox] = o;
+          }
+        }
+      }
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int k = 0; k < TN; ++k) {
+    const int ct = wn * WN + 16 * k + r16;   // column inside the block tile
+    const int col = n0 + ct;
+    const bool colok = col < a.cout;
+    const float bv = ((a.flags & DSR_F_BIAS) && colok) ? a.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * WM + 16 * i + 4 * g + r;
+        const float v = acc[i][k][r] + bv;
+        const float vm = (m0 + row < a.M && colok) ? v : 0.f;   // statistics ignore tail rows / pad columns
+        s1 += vm;
+        s2 += vm * vm;
+        const float o = colok ? act_apply(a.act, v, slope) : 0.f;
+        *reinterpret_cast<unsigned short*>(sC + row * C_STRIDE + ct * 2) = f2h<DT>(o);
+      }
+    }
+    if (do_stats) {
+      s1 += __shfl_xor(s1, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (g == 0) {
+        sStat[(wm * 2 + 0) * BN + ct] = s1;
+        sStat[(wm * 2 + 1) * BN + ct] = s2;
+      }
+    }
+  }
+  __syncthreads();
+
+  if (do_stats) {
+    for (int c = tid; c < 2 * BN; c += 256) {
+      int which = c / BN, ct = c % BN;
+      int col = n0 + ct;
+      if (col < a.cout) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) s += sStat[(w * 2 + which) * BN + ct];
+        a.stats[((size_t)tile_m * 2 + which) * a.stats_stride + col] = s;
+      }
+    }
+  }
+  unsigned short* __restrict__ Y = reinterpret_cast<unsigned short*>(a.y);
+  if (!(a.flags & DSR_F_PIXSHUF)) {
+    constexpr int CH = BN / 8;
+    for (int idx = tid; idx < BM * CH; idx += 256) {
+      int row = idx / CH, ch = idx % CH;
+      int m = m0 + row, col0 = n0 + ch * 8;
+      if (m < a.M && col0 < a.CoutP) {
+        int n = fd_div(a.fd_ghw, m);
+        int rem = m - n * (a.GH * a.GW);
+        int gy = fd_div(a.fd_gw, rem);
+        int gx = rem - gy * a.GW;
+        int oy = gy * a.osy + a.ooy, ox = gx * a.osx + a.oox;
+        size_t off = ((size_t)(n * a.OH + oy) * a.OW + ox) * a.CoutP + col0;
+        *reinterpret_cast<U4*>(Y + off) = *reinterpret_cast<const U4*>(sC + row * C_STRIDE + ch * 16);
+      }
+    }
+  } else {
+    // PixelShuffle(2): conv channel 4c+2i+j of grid pixel (h,w) -> channel c of pixel (2h+i, 2w+j)
+    if constexpr (BN >= 32) {
+      constexpr int CQ = BN / 32;   // 8-channel output chunks per sub-pixel in this tile
+      for (int idx = tid; idx < BM * 4 * CQ; idx += 256) {
+        int row = idx / (4 * CQ);
+        int rem2 = idx % (4 * CQ);
+        int sub = rem2 / CQ, cq = rem2 % CQ;
+        int m = m0 + row;
+        int oc0 = n0 / 4 + cq * 8;
+        if (m < a.M && oc0 < a.CoutP) {
+          int n = fd_div(a.fd_ghw, m);
+          int rem = m - n * (a.GH * a.GW);
+          int gy = fd_div(a.fd_gw, rem);
+          int gx = rem - gy * a.GW;
+          int oy = 2 * gy + (sub >> 1), ox = 2 * gx + (sub & 1);
+          const unsigned short* src = reinterpret_cast<const unsigned short*>(sC + row * C_STRIDE);
+          unsigned short v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = src[4 * (cq * 8 + q) + sub];
+          U4 o;
+          o.x = v[0] | ((unsigned)v[1] << 16);
+          o.y = v[2] | ((unsigned)v[3] << 16);
+          o.z = v[4] | ((unsigned)v[5] << 16);
+          o.w = v[6] | ((unsigned)v[7] << 16);
+          size_t off = ((size_t)(n * a.OH + oy) * a.OW + ox) * a.CoutP + oc0;
+          *reinterpret_cast<U4*>(Y + off) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int DT, int BM, int BN, int WGM, int WGN>
+static void launch_one(const ConvGemmArgs& a, hipStream_t st) {
+  ConvGemmArgs b = a;
+  b.tiles_m = (a.M + BM - 1) / BM;
+  b.tiles_n = (a.NB + BN - 1) / BN;
+  dim3 grid(b.tiles_m * b.tiles_n), block(256);
+  hipLaunchKernelGGL((conv_gemm_kernel<DT, BM, BN, WGM, WGN>), grid, block, 0, st, b);
+}
+
+int dsr_conv_gemm_bm(int /*NB*/) { return 128; }
+
+template <int DT>
+static void dispatch_dt(const ConvGemmArgs& a, hipStream_t st) {
+  if (a.NB > 64)
+    launch_one<DT, 128, 128, 2, 2>(a, st);
+  else if (a.NB > 16)
+    launch_one<DT, 128, 64, 2, 2>(a, st);
+  else
+    launch_one<DT, 128, 16, 4, 1>(a, st);
+}
+
+void dsr_launch_conv_gemm(const ConvGemmArgs& a, int dtype, hipStream_t st) {
+  if (dtype == DSR_DTYPE_BF16)
+    dispatch_dt<DSR_DTYPE_BF16>(a, st);
+  else
+    dispatch_dt<DSR_DTYPE_F16>(a, st);
+}

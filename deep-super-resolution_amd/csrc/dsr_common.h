@@ -1,0 +1,141 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) super-resolution kernels.
+// Activations are NHWC with the channel count padded to a multiple of 8 ("Cp"), 16-bit
+// storage (bf16 for training, f16 for inference), fp32 accumulation everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+#define DSR_DTYPE_BF16 0
+#define DSR_DTYPE_F16 1
+
+// activation codes shared by conv epilogues and the pointwise kernels
+#define DSR_ACT_NONE 0
+#define DSR_ACT_LEAKY 1   // slope passed by value
+#define DSR_ACT_PRELU 2   // slope read from a 1-element device tensor
+#define DSR_ACT_RELU 3
+#define DSR_ACT_TANH 4
+#define DSR_ACT_SIGMOID 5
+
+#define DSR_PAD_ZERO 0
+#define DSR_PAD_REFLECT 1
+#define DSR_PAD_REPLICATE 2
+
+// ---- 16-bit <-> fp32 (bit exact round-to-nearest-even; NaN stays NaN via the compiler cast)
+template <int DT>
+__device__ __forceinline__ float h2f(unsigned short h) {
+  if constexpr (DT == DSR_DTYPE_BF16) {
+    return __uint_as_float(((unsigned)h) << 16);
+  } else {
+    _Float16 v;
+    __builtin_memcpy(&v, &h, 2);
+    return (float)v;
+  }
+}
+template <int DT>
+__device__ __forceinline__ unsigned short f2h(float f) {
+  if constexpr (DT == DSR_DTYPE_BF16) {
+    __bf16 v = (__bf16)f;
+    unsigned short h;
+    __builtin_memcpy(&h, &v, 2);
+    return h;
+  } else {
+    _Float16 v = (_Float16)f;
+    unsigned short h;
+    __builtin_memcpy(&h, &v, 2);
+    return h;
+  }
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned U4;   // one 16-byte vector = 8 x 16-bit channels
+
+template <int DT>
+__device__ __forceinline__ void unpack8(const U4& v, float* f) {
+  f[0] = h2f<DT>((unsigned short)(v.x & 0xffff));
+  f[1] = h2f<DT>((unsigned short)(v.x >> 16));
+  f[2] = h2f<DT>((unsigned short)(v.y & 0xffff));
+  f[3] = h2f<DT>((unsigned short)(v.y >> 16));
+  f[4] = h2f<DT>((unsigned short)(v.z & 0xffff));
+  f[5] = h2f<DT>((unsigned short)(v.z >> 16));
+  f[6] = h2f<DT>((unsigned short)(v.w & 0xffff));
+  f[7] = h2f<DT>((unsigned short)(v.w >> 16));
+}
+template <int DT>
+__device__ __forceinline__ U4 pack8(const float* f) {
+  U4 v;
+  v.x = (unsigned)f2h<DT>(f[0]) | ((unsigned)f2h<DT>(f[1]) << 16);
+  v.y = (unsigned)f2h<DT>(f[2]) | ((unsigned)f2h<DT>(f[3]) << 16);
+  v.z = (unsigned)f2h<DT>(f[4]) | ((unsigned)f2h<DT>(f[5]) << 16);
+  v.w = (unsigned)f2h<DT>(f[6]) | ((unsigned)f2h<DT>(f[7]) << 16);
+  return v;
+}
+
+__device__ __forceinline__ float act_apply(int act, float v, float slope) {
+  // branch-light on purpose: this is inlined 64x in the conv epilogue.  tanh/sigmoid share one exp:
+  // sigmoid(t) = 1/(1+e^-t), tanh(v) = 2*sigmoid(2v) - 1 (abs error ~1e-7, saturates correctly).
+  if (act >= DSR_ACT_TANH) {   // wave-uniform
+    const float t = act == DSR_ACT_TANH ? 2.f * v : v;
+    const float sg = __fdividef(1.f, 1.f + __expf(-t));
+    return act == DSR_ACT_TANH ? 2.f * sg - 1.f : sg;
+  }
+  const float neg = act == DSR_ACT_RELU ? 0.f : (act == DSR_ACT_NONE ? v : v * slope);
+  return v >= 0.f ? v : neg;
+}
+// derivative expressed through the activation OUTPUT o (valid for slope > 0)
+__device__ __forceinline__ float act_grad_from_out(int act, float o, float slope) {
+  if (act == DSR_ACT_TANH) return 1.f - o * o;
+  if (act == DSR_ACT_SIGMOID) return o * (1.f - o);
+  if (act == DSR_ACT_NONE) return 1.f;
+  if (act == DSR_ACT_RELU) return o > 0.f ? 1.f : 0.f;
+  return o >= 0.f ? 1.f : slope;
+}
+
+__device__ __forceinline__ int pad_index(int i, int n, int mode, bool& inb) {
+  // maps a possibly out-of-range coordinate (branch-free); inb=false means "contributes zero"
+  const bool in = (unsigned)i < (unsigned)n;
+  const int refl = i < 0 ? -i : 2 * (n - 1) - i;
+  const int repl = i < 0 ? 0 : n - 1;
+  const int alt = mode == DSR_PAD_REFLECT ? refl : repl;
+  const bool alt_ok = (mode != DSR_PAD_ZERO) && ((unsigned)alt < (unsigned)n);
+  inb = inb && (in || alt_ok);
+  return in ? i : (alt_ok ? alt : 0);
+}
+
+// predicated 16-byte load without a branch: masked lanes read element 0 of the tensor (always mapped)
+__device__ __forceinline__ U4 load16_or_zero(const unsigned short* base, size_t off, bool ok) {
+  U4 v = *reinterpret_cast<const U4*>(base + (ok ? off : 0));
+  const U4 z = {0u, 0u, 0u, 0u};
+  return ok ? v : z;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// MFMA 16x16x32, bf16 or f16 operands (8 elements / lane), fp32 accumulate
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(const U4& a, const U4& b, f32x4 c) {
+  if constexpr (DT == DSR_DTYPE_BF16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
+                                                  0);
+  }
+}
+
+// XCD-aware, bijective block-id remap (consecutive logical tiles share an XCD's L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  int q = nwg / nx, r = nwg % nx;
+  int xcd = bid % nx, idx = bid / nx;
+  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

@@ -1,0 +1,75 @@
+// Internal launch interfaces shared by the .hip translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DSR_MAX_TAPS 96
+
+#define DSR_F_BIAS 1
+#define DSR_F_STATS 2
+#define DSR_F_PIXSHUF 4
+#define DSR_F_OUT_NCHW_F32 8
+#define DSR_F_PRELU_PTR 16
+
+// q = floor(m / d) for 0 <= m < 2^31 via multiply-high (no integer division in kernels)
+struct FastDiv {
+  unsigned magic;
+  unsigned shift;
+};
+static inline FastDiv fd_make(unsigned d) {
+  FastDiv f;
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shift = s;
+  f.magic = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+  return f;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ int fd_div(const FastDiv f, int m) {
+  return (int)((__umulhi((unsigned)m, f.magic) + (unsigned)m) >> f.shift);
+}
+#endif
+
+struct ConvGemmArgs {
+  const void* x;       // [N][IH][IW][CinP] 16-bit
+  const void* w;       // [slices][NB][CinP] 16-bit
+  void* y;             // [N][OH][OW][CoutP] 16-bit
+  float* out_f32;      // optional NCHW fp32 output [N][cout][OH][OW]
+  const float* bias;   // [cout]
+  const float* prelu;  // 1 float
+  float* stats;        // [tiles_m][2][stats_stride]
+  int M, GH, GW;
+  int IH, IW, CinP;
+  int OH, OW, CoutP;
+  int NB;     // weight rows per tap slice (>= cout, multiple of 8)
+  int cout;   // valid output columns
+  int stats_stride;
+  int isy, isx, osy, osx, ooy, oox;
+  int ntaps, CU, U, ksteps;
+  int pad_mode, act;
+  float slope;
+  int flags;
+  int tiles_m, tiles_n;
+  FastDiv fd_ghw, fd_gw, fd_cu;
+  int taps[DSR_MAX_TAPS];   // (dy & 0xff) | (dx & 0xff) << 8 | widx << 16
+};
+
+void dsr_launch_conv_gemm(const ConvGemmArgs& a, int dtype, hipStream_t st);
+
+struct WgradArgs {
+  const void* x;    // [N][IH][IW][CinP]
+  const void* dy;   // [N][OH][OW][CoutP]
+  float* partial;   // [splits][ntaps][CoutP][CinP] fp32
+  int M, OH, OW, IH, IW, CinP, CoutP;
+  int stride, pad, pad_mode, KH, KW;
+  int tiles_co, tiles_ci, splits, chunk;   // chunk = pixels per split (multiple of 128)
+  FastDiv fd_ohw, fd_ow;
+};
+void dsr_launch_wgrad(const WgradArgs& a, int dtype, hipStream_t st);
+
+void dsr_launch_wgrad_reduce(const float* partial, float* dw, int splits, int ntaps, int Cout, int Cin, int CoutP,
+                             int CinP, hipStream_t st);
+
+// records hipGetLastError() under `what`; returns 0 or a negative code (see dsr_last_error()).
+int dsr_launch_status(const char* what);
+int dsr_fail(int code, const char* fmt, ...);

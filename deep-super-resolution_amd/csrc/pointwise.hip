@@ -1,0 +1,698 @@
+// HBM-bound pointwise / reduction kernels around the convolutions (gfx950).
+// Everything works on NHWC 16-bit tensors with channels padded to 8, one 16-byte vector
+// (8 channels of one pixel) per access, fp32 math, and deterministic two-stage reductions
+// (per-block partial rows written with plain stores, summed by a finalize kernel) -- no atomics.
+//
+// Reference semantics covered here:
+//   nn.BatchNorm2d train/eval forward + backward      models/GAN/generator.py:8,12,53; discriminator.py:10;
+//                                                      models/DIP/utils.py:79-80
+//   PReLU(1) / LeakyReLU(0.2) / Tanh / Sigmoid / ReLU  generator.py:9,34,48,64; discriminator.py:12,27,41,45;
+//                                                      models/DIP/utils.py:68; skip.py:94
+//   residual add x + z                                 generator.py:23,74
+//   PixelShuffle(2) backward (un-shuffle)              generator.py:32,38
+#include "dsr_common.h"
+#include "dsr_kernels.h"
+#include "../../include/dsr_hip.h"
+
+// ------------------------------------------------------------------ layout conversion
+template <int DT>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int N, int C, int H,
+                                    int W, int Cp) {
+  // one thread = one pixel x 8-channel chunk
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int cpr = Cp / 8;
+  size_t total = (size_t)N * H * W * cpr;
+  if (idx >= total) return;
+  int ch = (int)(idx % cpr);
+  size_t pix = idx / cpr;
+  int hw = (int)(pix % ((size_t)H * W));
+  int n = (int)(pix / ((size_t)H * W));
+  float f[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int c = ch * 8 + k;
+    f[k] = c < C ? src[((size_t)n * C + c) * H * W + hw] : 0.f;
+  }
+  *reinterpret_cast<U4*>(dst + pix * Cp + ch * 8) = pack8<DT>(f);
+}
+
+template <int DT>
+__global__ void nhwc_to_nchw_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int N, int C, int H,
+                                    int W, int Cp) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)N * C * H * W;
+  if (idx >= total) return;
+  int hw = (int)(idx % ((size_t)H * W));
+  int c = (int)((idx / ((size_t)H * W)) % C);
+  int n = (int)(idx / ((size_t)H * W * C));
+  dst[idx] = h2f<DT>(src[((size_t)n * H * W + hw) * Cp + c]);
+}
+
+// ------------------------------------------------------------------ weight packing
+// w [Cout][Cin][KH][KW] fp32 -> fwd [T][NBo][CinP] and dgrad [T][NBi][CoutP] (16-bit, zero padded)
+template <int DT>
+__global__ void pack_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ wf,
+                                   unsigned short* __restrict__ wd, int Cout, int Cin, int T, int NBo, int CinP, int NBi,
+                                   int CoutP) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t nf = (size_t)T * NBo * CinP, nd = (size_t)T * NBi * CoutP;
+  if (idx < nf) {
+    int ci = (int)(idx % CinP);
+    int co = (int)((idx / CinP) % NBo);
+    int t = (int)(idx / ((size_t)CinP * NBo));
+    float v = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * T + t] : 0.f;
+    wf[idx] = f2h<DT>(v);
+  }
+  if (wd != nullptr && idx < nd) {
+    int co = (int)(idx % CoutP);
+    int ci = (int)((idx / CoutP) % NBi);
+    int t = (int)(idx / ((size_t)CoutP * NBi));
+    float v = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * T + t] : 0.f;
+    wd[idx] = f2h<DT>(v);
+  }
+}
+
+// ------------------------------------------------------------------ generic partial-row sum
+// out[c] = sum_b partial[b*stride_b + c]   (fp64 accumulate), optional scale
+__global__ void sum_rows_kernel(const float* __restrict__ partial, int rows, int row_stride, int C, float scale,
+                                float* __restrict__ out, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < rows; ++b) s += (double)partial[(size_t)b * row_stride + c];
+  float v = (float)(s * (double)scale);
+  out[c] = accumulate ? out[c] + v : v;
+}
+
+// ------------------------------------------------------------------ BatchNorm statistics -> affine
+// stats partial rows: [tiles][2][stride] (sum, sumsq) from the conv epilogue.
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int tiles, int stride, int C, float count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ num_batches, float momentum, float eps, int updates,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+                                   float* __restrict__ rstd_out, int Cp) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cp) return;
+  if (c >= C) {   // padded channels: identity-free zeros
+    scale[c] = 0.f;
+    shift[c] = 0.f;
+    mean_out[c] = 0.f;
+    rstd_out[c] = 0.f;
+    return;
+  }
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = 0; t < tiles; ++t) {
+    s1 += (double)partial[((size_t)t * 2 + 0) * stride + c];
+    s2 += (double)partial[((size_t)t * 2 + 1) * stride + c];
+  }
+  double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  mean_out[c] = (float)mean;
+  rstd_out[c] = rstd;
+  if (running_mean != nullptr) {
+    double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+    float rm = running_mean[c], rv = running_var[c];
+    for (int u = 0; u < updates; ++u) {
+      rm = (1.f - momentum) * rm + momentum * (float)mean;
+      rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+    }
+    running_mean[c] = rm;
+    running_var[c] = rv;
+  }
+  if (c == 0 && num_batches != nullptr) *num_batches += updates;
+}
+
+// eval mode: scale/shift from the running statistics
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      float eps, int C, int Cp, float* __restrict__ scale, float* __restrict__ shift,
+                                      float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cp) return;
+  if (c >= C) {
+    scale[c] = 0.f;
+    shift[c] = 0.f;
+    if (mean_out) mean_out[c] = 0.f;
+    if (rstd_out) rstd_out[c] = 0.f;
+    return;
+  }
+  float rstd = 1.f / sqrtf(running_var[c] + eps);
+  float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - running_mean[c] * sc;
+  if (mean_out) mean_out[c] = running_mean[c];
+  if (rstd_out) rstd_out[c] = rstd;
+}
+
+// channel statistics of a plain NHWC tensor (used where BN does not follow a conv: DIP's BN after Concat)
+template <int DT>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const unsigned short* __restrict__ x, size_t P, int Cp,
+                                                            int rows_per_block, float* __restrict__ partial) {
+  __shared__ float red[256 * 16];
+  const int cpr = Cp / 8;
+  const int tid = threadIdx.x;
+  const int rpi = 256 / cpr;                 // rows per iteration
+  const int ch = tid % cpr, rr = tid / cpr;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s1[k] = s2[k] = 0.f;
+  size_t p0 = (size_t)blockIdx.x * rows_per_block;
+  size_t p1 = p0 + rows_per_block;
+  if (p1 > P) p1 = P;
+  if (rr < rpi) {
+    for (size_t p = p0 + rr; p < p1; p += rpi) {
+      U4 v = *reinterpret_cast<const U4*>(x + p * Cp + ch * 8);
+      float f[8];
+      unpack8<DT>(v, f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        s1[k] += f[k];
+        s2[k] += f[k] * f[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    red[tid * 16 + k] = s1[k];
+    red[tid * 16 + 8 + k] = s2[k];
+  }
+  __syncthreads();
+  for (int c = tid; c < 2 * Cp; c += 256) {
+    int which = c / Cp, cc = c % Cp;
+    int chn = cc / 8, k = cc % 8;
+    float s = 0.f;
+    for (int r = 0; r < rpi; ++r) s += red[(r * cpr + chn) * 16 + which * 8 + k];
+    partial[((size_t)blockIdx.x * 2 + which) * Cp + cc] = s;
+  }
+}
+
+// ------------------------------------------------------------------ BN-apply + activation (+ residual)
+template <int DT>
+__global__ void bn_act_fwd_kernel(const unsigned short* __restrict__ y, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, const unsigned short* __restrict__ residual,
+                                  unsigned short* __restrict__ out, size_t nvec, int Cp, int act, float slope_v,
+                                  const float* __restrict__ prelu) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nvec) return;
+  const int cpr = Cp / 8;
+  const int ch = (int)(idx % cpr);
+  const float slope = prelu ? prelu[0] : slope_v;
+  float f[8], r[8];
+  unpack8<DT>(*reinterpret_cast<const U4*>(y + idx * 8), f);
+  if (residual) unpack8<DT>(*reinterpret_cast<const U4*>(residual + idx * 8), r);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int c = ch * 8 + k;
+    float v = scale ? f[k] * scale[c] + shift[c] : f[k];
+    v = act_apply(act, v, slope);
+    if (residual) v += r[k];
+    f[k] = v;
+  }
+  *reinterpret_cast<U4*>(out + idx * 8) = pack8<DT>(f);
+}
+
+// backward of out = act(scale*y + shift) [+ residual]; g = dout * act'(z).
+// pass 1: per-channel partial sums of g, g*xhat and the PReLU slope gradient sum(dout * z * [z<0]).
+template <int DT>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
+    const unsigned short* __restrict__ dout, const unsigned short* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd, size_t P, int Cp,
+    int rows_per_block, int act, float slope_v, const float* __restrict__ prelu, float* __restrict__ partial) {
+  __shared__ float red[256 * 24];
+  const int cpr = Cp / 8;
+  const int tid = threadIdx.x;
+  const int rpi = 256 / cpr;
+  const int ch = tid % cpr, rr = tid / cpr;
+  const float slope = prelu ? prelu[0] : slope_v;
+  float sg[8], sgx[8], sp[8];
+  float csc[8], csh[8], cm[8], cr[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sg[k] = sgx[k] = sp[k] = 0.f;
+    int c = (ch < cpr ? ch : 0) * 8 + k;
+    csc[k] = scale[c];
+    csh[k] = shift[c];
+    cm[k] = mean[c];
+    cr[k] = rstd[c];
+  }
+  size_t p0 = (size_t)blockIdx.x * rows_per_block;
+  size_t p1 = p0 + rows_per_block;
+  if (p1 > P) p1 = P;
+  if (rr < rpi) {
+    for (size_t p = p0 + rr; p < p1; p += rpi) {
+      float d[8], f[8];
+      unpack8<DT>(*reinterpret_cast<const U4*>(dout + p * Cp + ch * 8), d);
+      unpack8<DT>(*reinterpret_cast<const U4*>(y + p * Cp + ch * 8), f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float z = f[k] * csc[k] + csh[k];
+        float o = act_apply(act, z, slope);
+        float gg = d[k] * act_grad_from_out(act, (act == DSR_ACT_LEAKY || act == DSR_ACT_PRELU) ? z : o, slope);
+        float xh = (f[k] - cm[k]) * cr[k];
+        sg[k] += gg;
+        sgx[k] += gg * xh;
+        if (act == DSR_ACT_PRELU && z < 0.f) sp[k] += d[k] * z;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    red[tid * 24 + k] = sg[k];
+    red[tid * 24 + 8 + k] = sgx[k];
+    red[tid * 24 + 16 + k] = sp[k];
+  }
+  __syncthreads();
+  for (int c = tid; c < 3 * Cp; c += 256) {
+    int which = c / Cp, cc = c % Cp;
+    int chn = cc / 8, k = cc % 8;
+    float s = 0.f;
+    for (int r = 0; r < rpi; ++r) s += red[(r * cpr + chn) * 24 + which * 8 + k];
+    partial[((size_t)blockIdx.x * 3 + which) * Cp + cc] = s;
+  }
+}
+
+// finalize: dgamma = sum g*xhat, dbeta = sum g, dprelu = sum over channels; c1 = dbeta/n, c2 = dgamma/n
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int C, int Cp, float count,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ dprelu, float* __restrict__ c1, float* __restrict__ c2) {
+  __shared__ double sp[256];
+  int c = threadIdx.x;
+  double acc_p = 0.0;
+  for (int cc = c; cc < Cp; cc += blockDim.x) {
+    double g = 0.0, gx = 0.0, p = 0.0;
+    for (int b = 0; b < blocks; ++b) {
+      g += (double)partial[((size_t)b * 3 + 0) * Cp + cc];
+      gx += (double)partial[((size_t)b * 3 + 1) * Cp + cc];
+      p += (double)partial[((size_t)b * 3 + 2) * Cp + cc];
+    }
+    if (cc < C) {
+      if (dgamma) dgamma[cc] = (float)gx;
+      if (dbeta) dbeta[cc] = (float)g;
+      acc_p += p;
+    }
+    c1[cc] = cc < C ? (float)(g / count) : 0.f;
+    c2[cc] = cc < C ? (float)(gx / count) : 0.f;
+  }
+  sp[threadIdx.x] = acc_p;
+  __syncthreads();
+  if (threadIdx.x == 0 && dprelu) {
+    double s = 0.0;
+    for (int i = 0; i < (int)blockDim.x; ++i) s += sp[i];
+    dprelu[0] = (float)s;
+  }
+}
+
+// pass 2: dy = scale * (g - c1 - xhat * c2)      (scale = gamma * rstd)
+// with bn == 0 (no BatchNorm, scale == nullptr): dy = g
+template <int DT>
+__global__ void bn_act_bwd_apply_kernel(const unsigned short* __restrict__ dout, const unsigned short* __restrict__ y,
+                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                        const float* __restrict__ c1, const float* __restrict__ c2,
+                                        unsigned short* __restrict__ dy, size_t nvec, int Cp, int act, float slope_v,
+                                        const float* __restrict__ prelu, int train) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nvec) return;
+  const int cpr = Cp / 8;
+  const int ch = (int)(idx % cpr);
+  const float slope = prelu ? prelu[0] : slope_v;
+  float d[8], f[8];
+  unpack8<DT>(*reinterpret_cast<const U4*>(dout + idx * 8), d);
+  unpack8<DT>(*reinterpret_cast<const U4*>(y + idx * 8), f);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int c = ch * 8 + k;
+    float sc = scale[c];
+    float z = f[k] * sc + shift[c];
+    float o = act_apply(act, z, slope);
+    float gg = d[k] * act_grad_from_out(act, (act == DSR_ACT_LEAKY || act == DSR_ACT_PRELU) ? z : o, slope);
+    if (train) {
+      float xh = (f[k] - mean[c]) * rstd[c];
+      f[k] = sc * (gg - c1[c] - xh * c2[c]);
+    } else {
+      f[k] = sc * gg;   // eval mode: BN is a fixed affine map
+    }
+  }
+  *reinterpret_cast<U4*>(dy + idx * 8) = pack8<DT>(f);
+}
+
+// ------------------------------------------------------------------ activation backward for conv+act layers
+// dy[conv layout] = dout * act'(out), where out is the stored activation OUTPUT (valid for slope > 0).
+// pixshuf: out/dout are [N][2H][2W][Cq] and dy is [N][H][W][4*C] with channel 4c+2i+j <- pixel (2h+i,2w+j).
+// Also emits per-block partial rows: [blocks][2][CyP] = (bias grad column sums, PReLU-slope grad terms).
+template <int DT>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const unsigned short* __restrict__ dout,
+                                                      const unsigned short* __restrict__ out,
+                                                      unsigned short* __restrict__ dy, int N, int H, int W, int CyP,
+                                                      int CoP, int pixshuf, int act, float slope_v,
+                                                      const float* __restrict__ prelu, int rows_per_block,
+                                                      float* __restrict__ partial) {
+  __shared__ float red[256 * 16];
+  const int cpr = CyP / 8;
+  const int tid = threadIdx.x;
+  const int rpi = 256 / cpr;
+  const int ch = tid % cpr, rr = tid / cpr;
+  const float slope = prelu ? prelu[0] : slope_v;
+  float sb[8], sp[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sb[k] = sp[k] = 0.f;
+  const size_t P = (size_t)N * H * W;
+  size_t p0 = (size_t)blockIdx.x * rows_per_block;
+  size_t p1 = p0 + rows_per_block;
+  if (p1 > P) p1 = P;
+  if (rr < rpi) {
+    for (size_t p = p0 + rr; p < p1; p += rpi) {
+      float d[8], o[8];
+      if (!pixshuf) {
+        unpack8<DT>(*reinterpret_cast<const U4*>(dout + p * CoP + ch * 8), d);
+        unpack8<DT>(*reinterpret_cast<const U4*>(out + p * CoP + ch * 8), o);
+      } else {
+        int w = (int)(p % W);
+        int h = (int)((p / W) % H);
+        int n = (int)(p / ((size_t)W * H));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          int cy = ch * 8 + k;
+          int c = cy >> 2, i = (cy >> 1) & 1, jx = cy & 1;
+          size_t q = ((size_t)(n * 2 * H + 2 * h + i) * (2 * W) + 2 * w + jx) * CoP + c;
+          bool ok = c < CoP;
+          d[k] = ok ? h2f<DT>(dout[q]) : 0.f;
+          o[k] = ok ? h2f<DT>(out[q]) : 0.f;
+        }
+      }
+      float g[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        g[k] = d[k] * act_grad_from_out(act, o[k], slope);
+        sb[k] += g[k];
+        if (act == DSR_ACT_PRELU && o[k] < 0.f) sp[k] += d[k] * (o[k] / slope);
+      }
+      *reinterpret_cast<U4*>(dy + p * CyP + ch * 8) = pack8<DT>(g);
+    }
+  }
+  if (partial == nullptr) return;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    red[tid * 16 + k] = sb[k];
+    red[tid * 16 + 8 + k] = sp[k];
+  }
+  __syncthreads();
+  for (int c = tid; c < 2 * CyP; c += 256) {
+    int which = c / CyP, cc = c % CyP;
+    int chn = cc / 8, k = cc % 8;
+    float s = 0.f;
+    for (int r = 0; r < rpi; ++r) s += red[(r * cpr + chn) * 16 + which * 8 + k];
+    partial[((size_t)blockIdx.x * 2 + which) * CyP + cc] = s;
+  }
+}
+
+// final layer (fp32 NCHW output through tanh/sigmoid): dy NHWC16 [N][H][W][Cp] from NCHW fp32 dout/out
+template <int DT>
+__global__ void act_bwd_nchw_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                    unsigned short* __restrict__ dy, int N, int C, int H, int W, int Cp, int act) {
+  size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t P = (size_t)N * H * W;
+  if (pix >= P) return;
+  int hw = (int)(pix % ((size_t)H * W));
+  int n = (int)(pix / ((size_t)H * W));
+  for (int c0 = 0; c0 < Cp; c0 += 8) {
+    float g[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int c = c0 + k;
+      if (c < C) {
+        size_t q = ((size_t)n * C + c) * H * W + hw;
+        g[k] = dout[q] * act_grad_from_out(act, out[q], 0.f);
+      } else {
+        g[k] = 0.f;
+      }
+    }
+    *reinterpret_cast<U4*>(dy + pix * Cp + c0) = pack8<DT>(g);
+  }
+}
+
+// column sums of an NHWC tensor -> partial rows [blocks][Cp]  (bias gradients)
+template <int DT>
+__global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __restrict__ x, size_t P, int Cp,
+                                                     int rows_per_block, float* __restrict__ partial) {
+  __shared__ float red[256 * 8];
+  const int cpr = Cp / 8;
+  const int tid = threadIdx.x;
+  const int rpi = 256 / cpr;
+  const int ch = tid % cpr, rr = tid / cpr;
+  float s1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s1[k] = 0.f;
+  size_t p0 = (size_t)blockIdx.x * rows_per_block;
+  size_t p1 = p0 + rows_per_block;
+  if (p1 > P) p1 = P;
+  if (rr < rpi) {
+    for (size_t p = p0 + rr; p < p1; p += rpi) {
+      float f[8];
+      unpack8<DT>(*reinterpret_cast<const U4*>(x + p * Cp + ch * 8), f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s1[k] += f[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[tid * 8 + k] = s1[k];
+  __syncthreads();
+  for (int c = tid; c < Cp; c += 256) {
+    int chn = c / 8, k = c % 8;
+    float s = 0.f;
+    for (int r = 0; r < rpi; ++r) s += red[(r * cpr + chn) * 8 + k];
+    partial[(size_t)blockIdx.x * Cp + c] = s;
+  }
+}
+
+// out = a + b (16-bit NHWC), used for gradient joins of residual / skip branches
+template <int DT>
+__global__ void add_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b,
+                           unsigned short* __restrict__ out, size_t nvec) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nvec) return;
+  float x[8], y[8];
+  unpack8<DT>(*reinterpret_cast<const U4*>(a + idx * 8), x);
+  unpack8<DT>(*reinterpret_cast<const U4*>(b + idx * 8), y);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] += y[k];
+  *reinterpret_cast<U4*>(out + idx * 8) = pack8<DT>(x);
+}
+
+// ------------------------------------------------------------------ losses (fp32 NCHW, mean reduction)
+// mode 0: L1, 1: MSE.  Writes grad = d(mean loss)/d(pred) * gscale and per-block partial loss sums.
+__global__ __launch_bounds__(256) void diff_loss_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                        float* __restrict__ grad, size_t n, int mode, float inv_n,
+                                                        float* __restrict__ partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float d = pred[i] - tgt[i];
+    if (mode == 0) {
+      s += fabsf(d);
+      if (grad) grad[i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv_n;
+    } else {
+      s += d * d;
+      if (grad) grad[i] = 2.f * d * inv_n;
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// BCE against a constant target (0 or 1) on probabilities p[n]; log clamped at -100 (nn.BCELoss).
+// loss = mean; grad[i] = dloss/dp[i].  Single block (n = batch size).
+__global__ void bce_const_kernel(const float* __restrict__ p, int n, float target, float* __restrict__ loss,
+                                 float* __restrict__ grad, int accumulate) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float v = p[i];
+    float l1 = fmaxf(logf(v), -100.f), l0 = fmaxf(logf(1.f - v), -100.f);
+    s += -(target * l1 + (1.f - target) * l0);
+    if (grad) {
+      // d/dv of the clamped logs: zero where the clamp is active
+      float g1 = (logf(v) > -100.f) ? 1.f / v : 0.f;
+      float g0 = (logf(1.f - v) > -100.f) ? -1.f / (1.f - v) : 0.f;
+      grad[i] = -(target * g1 + (1.f - target) * g0) / (float)n;
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    t /= (float)n;
+    loss[0] = accumulate ? loss[0] + t : t;
+  }
+}
+
+// ------------------------------------------------------------------ Adam (torch.optim.Adam defaults, no weight decay)
+// step counter lives on the device so the launch is graph-capturable.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                            const int* __restrict__ step) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int t = *step;
+  float bc1 = 1.f - powf(b1, (float)t);
+  float bc2 = 1.f - powf(b2, (float)t);
+  float gi = g[i];
+  float mi = b1 * m[i] + (1.f - b1) * gi;
+  float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+__global__ void incr_kernel(int* step) { *step += 1; }
+
+// ================================================================== host launchers
+#define DT_SWITCH(dtype, CALL)                 \
+  if ((dtype) == DSR_DTYPE_BF16) {             \
+    constexpr int DT = DSR_DTYPE_BF16;         \
+    CALL;                                      \
+  } else {                                     \
+    constexpr int DT = DSR_DTYPE_F16;          \
+    CALL;                                      \
+  }
+
+static inline unsigned nblk(size_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+extern "C" int dsr_pw_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int Cp, hipStream_t st) {
+  size_t total = (size_t)N * H * W * (Cp / 8);
+  DT_SWITCH(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<DT>), dim3(nblk(total, 256)), dim3(256), 0, st, src,
+                                      (unsigned short*)dst, N, C, H, W, Cp));
+  return dsr_launch_status("dsr_pw_nchw_to_nhwc");
+}
+extern "C" int dsr_pw_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int H, int W, int Cp, hipStream_t st) {
+  size_t total = (size_t)N * C * H * W;
+  DT_SWITCH(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<DT>), dim3(nblk(total, 256)), dim3(256), 0, st,
+                                      (const unsigned short*)src, dst, N, C, H, W, Cp));
+  return dsr_launch_status("dsr_pw_nhwc_to_nchw");
+}
+extern "C" int dsr_pw_pack_weight(int dtype, const float* w, void* wf, void* wd, int Cout, int Cin, int T, int NBo, int CinP,
+                        int NBi, int CoutP, hipStream_t st) {
+  size_t nf = (size_t)T * NBo * CinP, nd = wd ? (size_t)T * NBi * CoutP : 0;
+  size_t total = nf > nd ? nf : nd;
+  DT_SWITCH(dtype, hipLaunchKernelGGL((pack_weight_kernel<DT>), dim3(nblk(total, 256)), dim3(256), 0, st, w,
+                                      (unsigned short*)wf, (unsigned short*)wd, Cout, Cin, T, NBo, CinP, NBi, CoutP));
+  return dsr_launch_status("dsr_pw_pack_weight");
+}
+extern "C" int dsr_pw_sum_rows(const float* partial, int rows, int row_stride, int C, float scale, float* out, int accumulate,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(nblk(C, 128)), dim3(128), 0, st, partial, rows, row_stride, C, scale, out,
+                     accumulate);
+  return dsr_launch_status("dsr_pw_sum_rows");
+}
+extern "C" int dsr_pw_bn_finalize(const float* partial, int tiles, int stride, int C, int Cp, float count, const float* gamma,
+                        const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, int updates,
+                        float* scale, float* shift, float* mean, float* rstd, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(Cp, 128)), dim3(128), 0, st, partial, tiles, stride, C, count, gamma,
+                     beta, rm, rv, nbt, momentum, eps, updates, scale, shift, mean, rstd, Cp);
+  return dsr_launch_status("dsr_pw_bn_finalize");
+}
+extern "C" int dsr_pw_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                           int Cp, float* scale, float* shift, float* mean, float* rstd, hipStream_t st) {
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(nblk(Cp, 128)), dim3(128), 0, st, gamma, beta, rm, rv, eps, C, Cp,
+                     scale, shift, mean, rstd);
+}
+extern "C" int dsr_pw_reduce_blocks(size_t P, int* rows_per_block) {
+  // enough blocks to fill 256 CUs a few times over, at least 64 rows each
+  size_t target = 2048;
+  size_t rpb = (P + target - 1) / target;
+  if (rpb < 64) rpb = 64;
+  *rows_per_block = (int)rpb;
+  return (int)((P + rpb - 1) / rpb);
+  return dsr_launch_status("dsr_pw_bn_eval_affine");
+}
+extern "C" int dsr_pw_channel_stats(int dtype, const void* x, size_t P, int Cp, int blocks, int rpb, float* partial,
+                          hipStream_t st) {
+  DT_SWITCH(dtype, hipLaunchKernelGGL((channel_stats_kernel<DT>), dim3(blocks), dim3(256), 0, st,
+                                      (const unsigned short*)x, P, Cp, rpb, partial));
+  return dsr_launch_status("dsr_pw_channel_stats");
+}
+extern "C" int dsr_pw_bn_act_fwd(int dtype, const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                       size_t P, int Cp, int act, float slope, const float* prelu, hipStream_t st) {
+  size_t nvec = P * (Cp / 8);
+  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<DT>), dim3(nblk(nvec, 256)), dim3(256), 0, st,
+                                      (const unsigned short*)y, scale, shift, (const unsigned short*)residual,
+                                      (unsigned short*)out, nvec, Cp, act, slope, prelu));
+  return dsr_launch_status("dsr_pw_bn_act_fwd");
+}
+extern "C" int dsr_pw_bn_act_bwd_reduce(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
+                              const float* mean, const float* rstd, size_t P, int Cp, int blocks, int rpb, int act,
+                              float slope, const float* prelu, float* partial, hipStream_t st) {
+  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DT>), dim3(blocks), dim3(256), 0, st,
+                                      (const unsigned short*)dout, (const unsigned short*)y, scale, shift, mean, rstd, P,
+                                      Cp, rpb, act, slope, prelu, partial));
+  return dsr_launch_status("dsr_pw_bn_act_bwd_reduce");
+}
+extern "C" int dsr_pw_bn_bwd_finalize(const float* partial, int blocks, int C, int Cp, float count, float* dgamma, float* dbeta,
+                            float* dprelu, float* c1, float* c2, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, blocks, C, Cp, count, dgamma, dbeta,
+                     dprelu, c1, c2);
+  return dsr_launch_status("dsr_pw_bn_bwd_finalize");
+}
+extern "C" int dsr_pw_bn_act_bwd_apply(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
+                             const float* mean, const float* rstd, const float* c1, const float* c2, void* dy, size_t P,
+                             int Cp, int act, float slope, const float* prelu, int train, hipStream_t st) {
+  size_t nvec = P * (Cp / 8);
+  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DT>), dim3(nblk(nvec, 256)), dim3(256), 0, st,
+                                      (const unsigned short*)dout, (const unsigned short*)y, scale, shift, mean, rstd, c1,
+                                      c2, (unsigned short*)dy, nvec, Cp, act, slope, prelu, train));
+  return dsr_launch_status("dsr_pw_bn_act_bwd_apply");
+}
+extern "C" int dsr_pw_act_bwd(int dtype, const void* dout, const void* out, void* dy, int N, int H, int W, int CyP, int CoP,
+                    int pixshuf, int act, float slope, const float* prelu, int blocks, int rpb, float* partial,
+                    hipStream_t st) {
+  DT_SWITCH(dtype, hipLaunchKernelGGL((act_bwd_kernel<DT>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dout,
+                                      (const unsigned short*)out, (unsigned short*)dy, N, H, W, CyP, CoP, pixshuf, act,
+                                      slope, prelu, rpb, partial));
+  return dsr_launch_status("dsr_pw_act_bwd");
+}
+extern "C" int dsr_pw_act_bwd_nchw(int dtype, const float* dout, const float* out, void* dy, int N, int C, int H, int W, int Cp,
+                         int act, hipStream_t st) {
+  size_t P = (size_t)N * H * W;
+  DT_SWITCH(dtype, hipLaunchKernelGGL((act_bwd_nchw_kernel<DT>), dim3(nblk(P, 256)), dim3(256), 0, st, dout, out,
+                                      (unsigned short*)dy, N, C, H, W, Cp, act));
+  return dsr_launch_status("dsr_pw_act_bwd_nchw");
+}
+extern "C" int dsr_pw_colsum(int dtype, const void* x, size_t P, int Cp, int blocks, int rpb, float* partial, hipStream_t st) {
+  DT_SWITCH(dtype, hipLaunchKernelGGL((colsum_kernel<DT>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)x, P,
+                                      Cp, rpb, partial));
+  return dsr_launch_status("dsr_pw_colsum");
+}
+extern "C" int dsr_pw_add(int dtype, const void* a, const void* b, void* out, size_t nvec, hipStream_t st) {
+  DT_SWITCH(dtype, hipLaunchKernelGGL((add_kernel<DT>), dim3(nblk(nvec, 256)), dim3(256), 0, st,
+                                      (const unsigned short*)a, (const unsigned short*)b, (unsigned short*)out, nvec));
+  return dsr_launch_status("dsr_pw_add");
+}
+extern "C" int dsr_pw_diff_loss(const float* pred, const float* tgt, float* grad, size_t n, int mode, float* partial, int blocks,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(diff_loss_kernel, dim3(blocks), dim3(256), 0, st, pred, tgt, grad, n, mode, 1.f / (float)n,
+                     partial);
+  return dsr_launch_status("dsr_pw_diff_loss");
+}
+extern "C" int dsr_pw_bce_const(const float* p, int n, float target, float* loss, float* grad, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(bce_const_kernel, dim3(1), dim3(256), 0, st, p, n, target, loss, grad, accumulate);
+  return dsr_launch_status("dsr_pw_bce_const");
+}
+extern "C" int dsr_pw_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                 const int* step, hipStream_t st) {
+  hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, step);
+  return dsr_launch_status("dsr_pw_adam");
+}
+extern "C" int dsr_pw_incr(int* step, hipStream_t st) {
+  hipLaunchKernelGGL(incr_kernel, dim3(1), dim3(1), 0, st, step);
+  return dsr_launch_status("dsr_pw_incr");
+}

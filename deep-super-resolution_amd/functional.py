@@ -1,0 +1,430 @@
+"""Autograd functions over the C ABI (include/dsr_hip.h): the device work behind the
+reference's nn.Module surface.
+
+Internal activation format: torch tensor [N, H, W, Cp] (NHWC, Cp = channels rounded up to 8),
+dtype bfloat16 (training) or float16 (inference).  Parameters stay fp32 in the reference's
+layouts, so state_dicts interchange with the reference.
+
+PyTorch is only plumbing here: it owns device memory, the stream and the autograd tape; every
+FLOP is a HIP kernel from csrc/.  Nothing in this file can run without the extension.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_LEAKY, ACT_NONE, ACT_PRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH, BF16, F16,  # noqa: F401
+                   PAD_REFLECT, PAD_REPLICATE, PAD_ZERO, ConvDesc, Epilogue, check)
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def r8(c):
+    return (c + 7) // 8 * 8
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float16:
+        return F16
+    raise TypeError(f"activation dtype must be bfloat16 or float16, got {t.dtype}")
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("deep-super-resolution_amd: tensors must live on the MI355X (cuda device); "
+                           "there is no CPU implementation of this path")
+
+
+# ----------------------------------------------------------------------------- weight images
+_pack_cache = {}
+
+
+def _version(p):
+    return (p._version, getattr(p, "_dsr_version", 0), p.data_ptr())
+
+
+def bump(p):
+    """Called by the fused optimiser after it rewrote a parameter through its raw pointer."""
+    p._dsr_version = getattr(p, "_dsr_version", 0) + 1
+
+
+def clear_pack_cache():
+    _pack_cache.clear()
+
+
+def packed_weights(weight, desc, dtype):
+    """16-bit [T][Cout_p][Cin_p] (forward) and [T][Cin_p][Cout_p] (dgrad) images of an OIHW fp32 weight."""
+    key = (id(weight), dtype, desc.KH, desc.KW)
+    ver = _version(weight)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    lib = _lib.lib()
+    nf = lib.dsr_conv_packed_elems(C.byref(desc), 0)
+    nd = lib.dsr_conv_packed_elems(C.byref(desc), 1)
+    wf = torch.empty(nf, dtype=dtype, device=weight.device)
+    wd = torch.empty(nd, dtype=dtype, device=weight.device)
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    check(lib.dsr_conv_pack_weight(C.byref(desc), _ptr(w), _ptr(wf), _ptr(wd), _stream()))
+    _pack_cache[key] = (ver, wf, wd)
+    return wf, wd
+
+
+def make_desc(x, cout, kh, kw, stride, pad, pad_mode, cin):
+    n, h, w, cp = x.shape
+    assert cp == r8(cin), (cp, cin)
+    return ConvDesc(_dt(x), n, h, w, cin, cout, kh, kw, stride, pad, pad_mode)
+
+
+def _out_hw(desc):
+    oh, ow = C.c_int(), C.c_int()
+    check(_lib.lib().dsr_conv_out_size(C.byref(desc), C.byref(oh), C.byref(ow)))
+    return oh.value, ow.value
+
+
+def _reduce_blocks(p):
+    rpb = C.c_int()
+    blocks = _lib.lib().dsr_pw_reduce_blocks(p, C.byref(rpb))
+    return blocks, rpb.value
+
+
+def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape):
+    lib = _lib.lib()
+    dx = dw = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        wsz = lib.dsr_conv_dgrad_workspace(C.byref(desc))
+        ws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=x.device)
+        check(lib.dsr_conv_dgrad(C.byref(desc), _ptr(dy), _ptr(wd), _ptr(dx), _ptr(ws), wsz, _stream()))
+    if need_dw:
+        dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
+        wsz = lib.dsr_conv_wgrad_workspace(C.byref(desc))
+        ws = torch.empty(wsz, dtype=torch.uint8, device=x.device)
+        check(lib.dsr_conv_wgrad(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), wsz, _stream()))
+    return dx, dw
+
+
+def _colsum(dy, c):
+    """fp32 [c] column sums of an NHWC tensor (bias gradient)."""
+    lib = _lib.lib()
+    p = dy.numel() // dy.shape[-1]
+    cp = dy.shape[-1]
+    blocks, rpb = _reduce_blocks(p)
+    part = torch.empty(blocks * cp, dtype=torch.float32, device=dy.device)
+    check(lib.dsr_pw_colsum(_dt(dy), _ptr(dy), p, cp, blocks, rpb, _ptr(part), _stream()))
+    out = torch.empty(c, dtype=torch.float32, device=dy.device)
+    check(lib.dsr_pw_sum_rows(_ptr(part), blocks, cp, c, 1.0, _ptr(out), 0, _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------- layout edges
+class ToNHWC(torch.autograd.Function):
+    """fp32 NCHW [N,C,H,W] -> 16-bit NHWC [N,H,W,r8(C)] (pad channels are zero)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        _need_gpu(x)
+        x = x.contiguous().float()
+        n, c, h, w = x.shape
+        out = torch.empty((n, h, w, r8(c)), dtype=dtype, device=x.device)
+        check(_lib.lib().dsr_pw_nchw_to_nhwc(_dt(out), _ptr(x), _ptr(out), n, c, h, w, r8(c), _stream()))
+        ctx.c = c
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        n, h, w, cp = g.shape
+        out = torch.empty((n, ctx.c, h, w), dtype=torch.float32, device=g.device)
+        check(_lib.lib().dsr_pw_nhwc_to_nchw(_dt(g), _ptr(g), _ptr(out), n, ctx.c, h, w, cp, _stream()))
+        return out, None
+
+
+class ToNCHW(torch.autograd.Function):
+    """16-bit NHWC -> fp32 NCHW with the first `c` channels."""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        x = x.contiguous()
+        n, h, w, cp = x.shape
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+        check(_lib.lib().dsr_pw_nhwc_to_nchw(_dt(x), _ptr(x), _ptr(out), n, c, h, w, cp, _stream()))
+        ctx.dtype = x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().float()
+        n, c, h, w = g.shape
+        out = torch.empty((n, h, w, r8(c)), dtype=ctx.dtype, device=g.device)
+        check(_lib.lib().dsr_pw_nchw_to_nhwc(_dt(out), _ptr(g), _ptr(out), n, c, h, w, r8(c), _stream()))
+        return out, None
+
+
+# ----------------------------------------------------------------------------- conv + bias + activation
+class ConvAct(torch.autograd.Function):
+    """y = act(conv(x, W) + b), optionally stored through PixelShuffle(2).
+
+    generator.py:47-48 (9x9 + PReLU), :30-39 (3x3 64->256 + PixelShuffle + PReLU: a one-parameter
+    PReLU commutes with the shuffle permutation), discriminator.py:25-27 (3x3 + LeakyReLU),
+    utils/GAN.py:19-57 (VGG 3x3 + ReLU), plain convs (act none).
+    Backward derives act' from the stored OUTPUT, which needs a positive PReLU/LeakyReLU slope."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, prelu, cfg):
+        _need_gpu(x)
+        x = x.contiguous()
+        cout, cin, kh, kw = weight.shape
+        desc = make_desc(x, cout, kh, kw, cfg["stride"], cfg["pad"], cfg.get("pad_mode", PAD_ZERO), cin)
+        oh, ow = _out_hw(desc)
+        wf, wd = packed_weights(weight, desc, x.dtype)
+        ps = bool(cfg.get("pixel_shuffle", False))
+        n = x.shape[0]
+        if ps:
+            y = torch.empty((n, 2 * oh, 2 * ow, r8(cout // 4)), dtype=x.dtype, device=x.device)
+        else:
+            y = torch.empty((n, oh, ow, r8(cout)), dtype=x.dtype, device=x.device)
+        act = cfg.get("act", ACT_NONE)
+        ep = Epilogue(act, float(cfg.get("slope", 0.0)), _ptr(prelu), _ptr(bias), None, int(ps), None)
+        check(_lib.lib().dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y), _stream()))
+        ctx.desc, ctx.cfg, ctx.ps, ctx.act = desc, cfg, ps, act
+        ctx.wshape = tuple(weight.shape)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, y, wd, prelu if prelu is not None else torch.empty(0, device=x.device))
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, wd, prelu = ctx.saved_tensors
+        prelu = prelu if prelu.numel() else None
+        lib = _lib.lib()
+        desc = ctx.desc
+        dout = dout.contiguous()
+        cout = desc.Cout
+        n = x.shape[0]
+        oh, ow = _out_hw(desc)
+        cyp = r8(cout)
+        need_partial = ctx.has_bias or prelu is not None
+        if ctx.act == ACT_NONE and not ctx.ps:
+            dy = dout
+            db = _colsum(dy, cout) if ctx.has_bias else None
+            dprelu = None
+        else:
+            dy = torch.empty((n, oh, ow, cyp), dtype=x.dtype, device=x.device)
+            p = n * oh * ow
+            blocks, rpb = _reduce_blocks(p)
+            part = torch.empty(blocks * 2 * cyp, dtype=torch.float32, device=x.device) if need_partial else None
+            check(lib.dsr_pw_act_bwd(_dt(x), _ptr(dout), _ptr(y), _ptr(dy), n, oh, ow, cyp, y.shape[-1], int(ctx.ps),
+                                     ctx.act, float(ctx.cfg.get("slope", 0.0)), _ptr(prelu), blocks, rpb, _ptr(part),
+                                     _stream()))
+            db = dprelu = None
+            if ctx.has_bias:
+                db = torch.empty(cout, dtype=torch.float32, device=x.device)
+                check(lib.dsr_pw_sum_rows(_ptr(part), blocks, 2 * cyp, cout, 1.0, _ptr(db), 0, _stream()))
+            if prelu is not None:
+                chan = torch.empty(cyp, dtype=torch.float32, device=x.device)
+                check(lib.dsr_pw_sum_rows(_ptr(part[cyp:]), blocks, 2 * cyp, cyp, 1.0, _ptr(chan), 0, _stream()))
+                dprelu = torch.empty(1, dtype=torch.float32, device=x.device)
+                check(lib.dsr_pw_sum_rows(_ptr(chan), cyp, 1, 1, 1.0, _ptr(dprelu), 0, _stream()))
+        dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape)
+        return dx, dw, db, dprelu, None
+
+
+# ----------------------------------------------------------------------------- conv + BatchNorm + activation (+ residual)
+class ConvBNAct(torch.autograd.Function):
+    """out = act(BN(conv(x, W) + b)) [+ residual]   (train or eval mode BatchNorm2d).
+
+    generator.py:14-25,71-74 (conv3x3 -> BN -> PReLU | + skip), discriminator.py:14-19
+    (conv3x3 s1|s2 -> BN -> LeakyReLU), models/DIP/skip.py:54-88 (reflect conv -> BN -> LeakyReLU).
+    The conv epilogue emits per-channel sum / sum-of-squares partial rows from its fp32
+    accumulators; a tiny finalize kernel turns them into the affine map and updates the running
+    statistics (momentum 0.1, unbiased variance) exactly like nn.BatchNorm2d."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, nbt, prelu, residual, cfg):
+        _need_gpu(x)
+        lib = _lib.lib()
+        x = x.contiguous()
+        cout, cin, kh, kw = weight.shape
+        desc = make_desc(x, cout, kh, kw, cfg["stride"], cfg["pad"], cfg.get("pad_mode", PAD_ZERO), cin)
+        oh, ow = _out_hw(desc)
+        wf, wd = packed_weights(weight, desc, x.dtype)
+        n = x.shape[0]
+        cp = r8(cout)
+        train = bool(cfg["train"])
+        dev = x.device
+        y = torch.empty((n, oh, ow, cp), dtype=x.dtype, device=dev)
+        scale = torch.empty(cp, dtype=torch.float32, device=dev)
+        shift = torch.empty(cp, dtype=torch.float32, device=dev)
+        mean = torch.empty(cp, dtype=torch.float32, device=dev)
+        rstd = torch.empty(cp, dtype=torch.float32, device=dev)
+        count = n * oh * ow
+        if train:
+            rows = lib.dsr_conv_stats_rows(C.byref(desc))
+            part = torch.empty(rows * 2 * cp, dtype=torch.float32, device=dev)
+            ep = Epilogue(ACT_NONE, 0.0, None, _ptr(bias), _ptr(part), 0, None)
+            check(lib.dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y), _stream()))
+            check(lib.dsr_pw_bn_finalize(_ptr(part), rows, cp, cout, cp, float(count), _ptr(gamma), _ptr(beta),
+                                         _ptr(running_mean), _ptr(running_var), _ptr(nbt), BN_MOMENTUM, BN_EPS, 1,
+                                         _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
+        else:
+            ep = Epilogue(ACT_NONE, 0.0, None, _ptr(bias), None, 0, None)
+            check(lib.dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y), _stream()))
+            check(lib.dsr_pw_bn_eval_affine(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), BN_EPS,
+                                            cout, cp, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
+        act = cfg.get("act", ACT_NONE)
+        out = torch.empty_like(y)
+        res = residual.contiguous() if residual is not None else None
+        check(lib.dsr_pw_bn_act_fwd(_dt(x), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), count, cp, act,
+                                    float(cfg.get("slope", 0.0)), _ptr(prelu), _stream()))
+        ctx.desc, ctx.cfg, ctx.act, ctx.train, ctx.count = desc, cfg, act, train, count
+        ctx.wshape = tuple(weight.shape)
+        ctx.has_res = residual is not None
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, y, wd, scale, shift, mean, rstd,
+                              prelu if prelu is not None else torch.empty(0, device=dev))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, wd, scale, shift, mean, rstd, prelu = ctx.saved_tensors
+        prelu = prelu if prelu.numel() else None
+        lib = _lib.lib()
+        desc = ctx.desc
+        dout = dout.contiguous()
+        cout = desc.Cout
+        cp = y.shape[-1]
+        dev = x.device
+        p = ctx.count
+        slope = float(ctx.cfg.get("slope", 0.0))
+        c1 = torch.empty(cp, dtype=torch.float32, device=dev)
+        c2 = torch.empty(cp, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(cout, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(cout, dtype=torch.float32, device=dev)
+        dprelu = torch.empty(1, dtype=torch.float32, device=dev) if prelu is not None else None
+        blocks, rpb = _reduce_blocks(p)
+        part = torch.empty(blocks * 3 * cp, dtype=torch.float32, device=dev)
+        check(lib.dsr_pw_bn_act_bwd_reduce(_dt(x), _ptr(dout), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean),
+                                           _ptr(rstd), p, cp, blocks, rpb, ctx.act, slope, _ptr(prelu), _ptr(part),
+                                           _stream()))
+        check(lib.dsr_pw_bn_bwd_finalize(_ptr(part), blocks, cout, cp, float(p), _ptr(dgamma), _ptr(dbeta),
+                                         _ptr(dprelu), _ptr(c1), _ptr(c2), _stream()))
+        dy = torch.empty_like(y)
+        check(lib.dsr_pw_bn_act_bwd_apply(_dt(x), _ptr(dout), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
+                                          _ptr(c1), _ptr(c2), _ptr(dy), p, cp, ctx.act, slope, _ptr(prelu),
+                                          int(ctx.train), _stream()))
+        dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape)
+        db = None
+        if ctx.has_bias:
+            # a bias in front of a train-mode BatchNorm has an analytically zero gradient (the reference holds
+            # ~1e-9 rounding noise there); in eval mode it is the column sum of dy.
+            db = torch.zeros(cout, dtype=torch.float32, device=dev) if ctx.train else _colsum(dy, cout)
+        dres = dout if ctx.has_res else None
+        return dx, dw, db, dgamma, dbeta, None, None, None, dprelu, dres, None
+
+
+# ----------------------------------------------------------------------------- last layer: conv + act -> fp32 NCHW
+class ConvOutNCHW(torch.autograd.Function):
+    """fp32 NCHW output of the last conv (+Tanh: generator.py:78-80; +Sigmoid: models/DIP/skip.py:92-94)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cfg):
+        _need_gpu(x)
+        x = x.contiguous()
+        cout, cin, kh, kw = weight.shape
+        desc = make_desc(x, cout, kh, kw, cfg["stride"], cfg["pad"], cfg.get("pad_mode", PAD_ZERO), cin)
+        oh, ow = _out_hw(desc)
+        wf, wd = packed_weights(weight, desc, x.dtype)
+        out = torch.empty((x.shape[0], cout, oh, ow), dtype=torch.float32, device=x.device)
+        act = cfg.get("act", ACT_NONE)
+        ep = Epilogue(act, 0.0, None, _ptr(bias), None, 0, _ptr(out))
+        check(_lib.lib().dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), None, _stream()))
+        ctx.desc, ctx.act = desc, act
+        ctx.wshape = tuple(weight.shape)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, out, wd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out, wd = ctx.saved_tensors
+        desc = ctx.desc
+        dout = dout.contiguous().float()
+        n, c, h, w = out.shape
+        dy = torch.empty((n, h, w, r8(c)), dtype=x.dtype, device=x.device)
+        check(_lib.lib().dsr_pw_act_bwd_nchw(_dt(x), _ptr(dout), _ptr(out), _ptr(dy), n, c, h, w, r8(c), ctx.act,
+                                             _stream()))
+        dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape)
+        db = _colsum(dy, c) if ctx.has_bias else None
+        return dx, dw, db, None
+
+
+# ----------------------------------------------------------------------------- losses
+class DiffLoss(torch.autograd.Function):
+    """mean |a-b| (mode 0, BASELINE config 2) or mean (a-b)^2 (mode 1, nn.MSELoss: DIP.py:26,65;
+    utils/GAN.py:74,90) over fp32 tensors; gradient w.r.t. the first argument only."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mode):
+        _need_gpu(pred)
+        pred = pred.contiguous().float()
+        target = target.contiguous().float()
+        n = pred.numel()
+        blocks = max(1, min(1024, (n + 1023) // 1024))
+        part = torch.empty(blocks, dtype=torch.float32, device=pred.device)
+        grad = torch.empty_like(pred)
+        lib = _lib.lib()
+        check(lib.dsr_pw_diff_loss(_ptr(pred), _ptr(target), _ptr(grad), n, mode, _ptr(part), blocks, _stream()))
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        check(lib.dsr_pw_sum_rows(_ptr(part), blocks, 1, 1, 1.0 / n, _ptr(loss), 0, _stream()))
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def l1_loss(pred, target):
+    return DiffLoss.apply(pred, target, 0)
+
+
+def mse_loss(pred, target):
+    return DiffLoss.apply(pred, target, 1)
+
+
+class BCEConst(torch.autograd.Function):
+    """nn.BCELoss()(p, full_like(p, target)) with the log clamp at -100 (utils/GAN.py:96-105)."""
+
+    @staticmethod
+    def forward(ctx, p, target):
+        _need_gpu(p)
+        p = p.contiguous().float()
+        loss = torch.empty(1, dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p)
+        check(_lib.lib().dsr_pw_bce_const(_ptr(p), p.numel(), float(target), _ptr(loss), _ptr(grad), 0, _stream()))
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+def bce_const(p, target):
+    return BCEConst.apply(p, target)

@@ -1,0 +1,42 @@
+"""Adam with torch.optim.Adam's default semantics (train_GAN.py:35-36, utils/DIP.py:34) as one fused
+HIP kernel per tensor; the step counter lives on the device so a whole train step can be captured
+in a HIP graph."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .functional import _ptr, _stream, bump, check
+
+
+class FusedAdam:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")   # torch.optim raises the same
+        self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        dev = self.params[0].device
+        self.m = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
+        self.v = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def step(self):
+        lib = _lib.lib()
+        st = _stream()
+        check(lib.dsr_pw_incr(_ptr(self.step_t), st))
+        for p, m, v in zip(self.params, self.m, self.v):
+            if p.grad is None:
+                continue
+            g = p.grad
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.float().contiguous()
+            check(lib.dsr_pw_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), self.lr, self.betas[0], self.betas[1],
+                                  self.eps, _ptr(self.step_t), st))
+            bump(p)

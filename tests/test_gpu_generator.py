@@ -1,0 +1,130 @@
+"""GPU: the HIP-backed Generator module (reference surface) against the CPU oracle and the golden
+vectors captured from the reference.  bf16 storage => tolerances are stated per quantity:
+  forward (tanh output in (-1,1)): max abs error <= 0.06, PSNR(hip, oracle) >= 34 dB at range 2
+  gradients: cosine similarity >= 0.98 and norm ratio within 10 % (they pass through 4..32 train-mode
+  BatchNorms whose backward amplifies rounding noise; element-wise comparison is meaningless there)
+  BatchNorm running statistics: 2 % relative.
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import filler, gan, losses, recipes
+
+pytestmark = pytest.mark.gpu
+PKG = "deep-super-resolution_amd"
+
+
+def P(sub):
+    return importlib.import_module(PKG + "." + sub)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    P("_lib").lib()
+    return torch.device("cuda:0")
+
+
+def cos(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-30))
+
+
+def build(dev, factor, nres, salt=0):
+    gen = P("models.GAN.generator")
+    sd = filler.fill_state_dict(gan.template(gan.generator_shapes(factor, nres)), salt)
+    g = gen.Generator(factor, nres)
+    assert list(g.state_dict().keys()) == list(sd.keys())          # reference key names and order
+    assert all(tuple(g.state_dict()[k].shape) == tuple(sd[k].shape) for k in sd)
+    g.load_state_dict(sd)
+    return g.to(dev), sd
+
+
+@pytest.mark.parametrize("factor,nres,shape", [(4, 2, (2, 3, 24, 24)), (2, 1, (3, 3, 16, 20)), (8, 2, (1, 3, 16, 16)),
+                                               (4, 16, (2, 3, 24, 24))])
+def test_generator_train_fwd_bwd(dev, factor, nres, shape):
+    g, sd = build(dev, factor, nres)
+    g.train()
+    x = filler.tensor(f"in:gen{factor}{nres}", shape, 0.5, 0.5)
+    xg = x.to(dev).requires_grad_(True)
+    y = g(xg)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (shape[0], 3, shape[2] * factor, shape[3] * factor)
+    probe = filler.tensor(f"probe:gen{factor}{nres}", tuple(y.shape))
+    (y * probe.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    # oracle, fp32 CPU
+    osd = {k: v.clone() for k, v in sd.items()}
+    recipes.leaves(osd)
+    xr = x.clone().requires_grad_(True)
+    yr = gan.generator_forward(osd, xr, True)
+    (yr * probe).sum().backward()
+    err = (y.detach().cpu() - yr.detach()).abs().max().item()
+    psnr = losses.psnr(y.detach().cpu(), yr.detach())
+    assert err <= 0.06 and psnr >= 34.0, (err, psnr)
+    gx = xg.grad.cpu()
+    assert cos(gx, xr.grad) >= 0.98, cos(gx, xr.grad)
+    bad = []
+    for k, p in g.named_parameters():
+        ref = osd[k].grad
+        if ref.abs().sum() < 1e-3 * max(1.0, ref.numel() ** 0.5):     # pre-BN biases: analytically zero
+            continue
+        c = cos(p.grad.cpu(), ref)
+        ratio = float(p.grad.norm().cpu() / ref.norm())
+        if c < 0.98 or not (0.9 < ratio < 1.1):
+            bad.append((k, c, ratio))
+    assert not bad, bad
+    for k, v in g.state_dict().items():
+        if "running_" in k:
+            r = osd[k]
+            assert float((v.cpu() - r).abs().max() / r.abs().max()) < 2e-2, k
+        if "num_batches" in k:
+            assert int(v) == int(osd[k])
+
+
+def test_generator_eval_matches_golden(dev, golden):
+    """Eval mode (running statistics): compare with the reference's own float64 output."""
+    z = golden("generator_g4_r2")
+    g, _ = build(dev, 4, 2)
+    g.eval()
+    x = filler.tensor("in:g4_r2", (2, 3, 8, 8), 0.5, 0.5)
+    with torch.no_grad():
+        y = g(x.to(dev))
+    torch.cuda.synchronize()
+    err = np.abs(y.cpu().numpy() - z["y_eval"]).max()
+    assert err <= 0.06, err
+
+
+def test_generator_fp16_inference(dev):
+    g, sd = build(dev, 8, 2)
+    g.eval()
+    g.compute_dtype = torch.float16
+    for m in g.modules():
+        if hasattr(m, "compute_dtype"):
+            m.compute_dtype = torch.float16
+    x = filler.tensor("in:gen_fp16", (1, 3, 24, 24), 0.5, 0.5)
+    with torch.no_grad():
+        y = g(x.to(dev))
+    torch.cuda.synchronize()
+    yr = gan.generator_forward({k: v.clone() for k, v in sd.items()}, x, False)
+    assert (y.cpu() - yr).abs().max().item() <= 0.02          # fp16 has 3 more mantissa bits than bf16
+
+
+def test_gen_l1_trajectory(dev):
+    """BASELINE config-2 step recipe: 4 Adam steps, PSNR delta vs the fp32 oracle <= 0.02 dB."""
+    optim, steps = P("optim"), P("steps")
+    g, sd = build(dev, 4, 2)
+    g.train()
+    opt = optim.FusedAdam(g.parameters(), lr=1e-4)
+    st = recipes.GenOnlyState({k: v.clone() for k, v in sd.items()}, lr=1e-4)
+    lr = filler.tensor("in:traj_lr", (4, 3, 24, 24), 0.5, 0.5)
+    hr = filler.tensor("in:traj_hr", (4, 3, 96, 96))
+    for _ in range(4):
+        loss, fake = steps.gen_l1_step(g, opt, lr.to(dev), hr.to(dev))
+        rloss, rfake = recipes.gen_l1_step(st, lr, hr)
+        assert abs(loss.item() - rloss) < 5e-3 * abs(rloss), (loss.item(), rloss)
+        dpsnr = abs(losses.psnr(fake.cpu(), hr) - losses.psnr(rfake, hr))
+        assert dpsnr <= 0.02, dpsnr

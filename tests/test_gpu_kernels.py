@@ -1,0 +1,320 @@
+"""GPU parity tests of the HIP kernels (through the C ABI) against a plain PyTorch fp32 CPU
+reference of the same op on the same bf16-rounded operands.
+
+Tolerances: operands are exactly representable in bf16 on both sides, accumulation is fp32 on
+both sides, so a single op differs only by the final bf16 rounding of the output (2^-9 relative)
+and by summation order.  Gradients w.r.t. weights are fp32 outputs.
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from oracle import filler
+
+pytestmark = pytest.mark.gpu
+
+PKG = "deep-super-resolution_amd"
+
+
+def P(sub):
+    return importlib.import_module(PKG + "." + sub)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    P("_lib").lib()          # raises if the extension is missing: no silent fallback
+    return torch.device("cuda:0")
+
+
+def bfr(t):
+    return t.to(torch.bfloat16).float()
+
+
+def rel_err(got, ref):
+    got, ref = got.double(), ref.double()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-20))
+
+
+def to_nhwc(x, cp=None):
+    n, c, h, w = x.shape
+    cp = cp or (c + 7) // 8 * 8
+    out = torch.zeros(n, h, w, cp, dtype=torch.bfloat16)
+    out[..., :c] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    return out
+
+
+def from_nhwc(y, c):
+    return y[..., :c].float().permute(0, 3, 1, 2).contiguous()
+
+
+def pad_ref(x, pad, mode):
+    if pad == 0:
+        return x
+    if mode == 0:
+        return TF.pad(x, (pad,) * 4)
+    return TF.pad(x, (pad,) * 4, mode="reflect" if mode == 1 else "replicate")
+
+
+def act_ref(F, y, act, slope):
+    if act == F.ACT_NONE:
+        return y
+    if act in (F.ACT_LEAKY, F.ACT_PRELU):
+        return torch.where(y >= 0, y, y * slope)
+    if act == F.ACT_RELU:
+        return torch.relu(y)
+    if act == F.ACT_TANH:
+        return torch.tanh(y)
+    return torch.sigmoid(y)
+
+
+CONV_CASES = [
+    # name, N, Cin, Cout, H, W, k, stride, pad, pad_mode, act
+    ("trunk3x3", 2, 64, 64, 12, 20, 3, 1, 1, 0, "none"),
+    ("trunk3x3_tail", 1, 64, 64, 7, 9, 3, 1, 1, 0, "leaky"),
+    ("head9x9", 2, 3, 64, 16, 16, 9, 1, 4, 0, "prelu"),
+    ("d_first", 2, 3, 64, 16, 24, 3, 1, 1, 0, "leaky"),
+    ("d_s2_64", 2, 64, 64, 16, 16, 3, 2, 1, 0, "none"),
+    ("d_s2_odd", 1, 64, 128, 15, 17, 3, 2, 1, 0, "none"),
+    ("d_128_256", 1, 128, 256, 8, 8, 3, 1, 1, 0, "relu"),
+    ("d_512", 1, 256, 512, 6, 6, 3, 1, 1, 0, "none"),
+    ("dip_reflect_s2", 1, 32, 128, 16, 16, 3, 2, 1, 1, "none"),
+    ("dip_reflect_132", 1, 132, 128, 10, 12, 3, 1, 1, 1, "none"),
+    ("dip_1x1_skip", 1, 32, 4, 12, 12, 1, 1, 0, 1, "none"),
+    ("dip_1x1_128", 2, 128, 128, 8, 8, 1, 1, 0, 0, "leaky"),
+    ("cout3_9x9", 1, 64, 3, 12, 12, 9, 1, 4, 0, "none"),
+    ("vgg_3_64", 1, 3, 64, 14, 14, 3, 1, 1, 0, "relu"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_act_fwd_bwd(dev, case):
+    F = P("functional")
+    name, n, cin, cout, h, w, k, stride, pad, pmode, actn = case
+    act = dict(none=F.ACT_NONE, leaky=F.ACT_LEAKY, prelu=F.ACT_PRELU, relu=F.ACT_RELU)[actn]
+    slope = 0.2 if actn == "leaky" else 0.25
+    x = bfr(filler.tensor("x:" + name, (n, cin, h, w)))
+    wt = bfr(filler.tensor("w:" + name, (cout, cin, k, k), float(np.sqrt(3.0 / (cin * k * k)))))
+    b = filler.tensor("b:" + name, (cout,), 0.1)
+    # ---- CPU reference (fp32)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    ar = torch.tensor([slope], requires_grad=True)
+    yr = TF.conv2d(pad_ref(xr, pad, pmode), wr, br, stride=stride)
+    yr = act_ref(F, yr, act, ar if act == F.ACT_PRELU else slope)
+    probe = bfr(filler.tensor("p:" + name, tuple(yr.shape)))
+    (yr * probe).sum().backward()
+    # ---- HIP
+    xg = to_nhwc(x).to(dev).requires_grad_(True)
+    wg = wt.to(dev).requires_grad_(True)
+    bg = b.to(dev).requires_grad_(True)
+    ag = torch.tensor([slope], device=dev, requires_grad=True) if act == F.ACT_PRELU else None
+    cfg = dict(stride=stride, pad=pad, pad_mode=pmode, act=act, slope=slope)
+    yg = F.ConvAct.apply(xg, wg, bg, ag, cfg)
+    yg.backward(to_nhwc(probe, yg.shape[-1]).to(dev))
+    torch.cuda.synchronize()
+    y = from_nhwc(yg.detach().cpu(), cout)
+    assert rel_err(y, yr.detach()) < 1.2e-2, ("fwd", rel_err(y, yr.detach()))
+    # pad channels of the output must be exactly zero (they feed the next layer's K dimension)
+    if yg.shape[-1] > cout:
+        assert float(yg.detach()[..., cout:].float().abs().max()) == 0.0
+    # the CPU reference back-propagates the fp32 pre-rounding output; the HIP path rounds dy to bf16
+    assert rel_err(from_nhwc(xg.grad.cpu(), cin), xr.grad) < 2.5e-2, ("dgrad", rel_err(from_nhwc(xg.grad.cpu(), cin), xr.grad))
+    assert rel_err(wg.grad.cpu(), wr.grad) < 2.5e-2, ("wgrad", rel_err(wg.grad.cpu(), wr.grad))
+    assert rel_err(bg.grad.cpu(), br.grad) < 2.5e-2, ("bias grad", rel_err(bg.grad.cpu(), br.grad))
+    if ag is not None:
+        assert rel_err(ag.grad.cpu(), ar.grad) < 3e-2, ("prelu grad", ag.grad.cpu(), ar.grad)
+
+
+def test_conv_exact_integers(dev):
+    """Small-integer operands make every product and partial sum exact: the MFMA lane maps, the LDS
+    swizzle, the tap table and the epilogue must then reproduce the reference bit for bit."""
+    F = P("functional")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-3, 4, (2, 64, 10, 13), generator=g).float()
+    wt = torch.randint(-2, 3, (64, 64, 3, 3), generator=g).float()
+    b = torch.randint(-4, 5, (64,), generator=g).float()
+    yr = TF.conv2d(x, wt, b, padding=1)
+    yr_b = bfr(yr)
+    yg = F.ConvAct.apply(to_nhwc(x).to(dev), wt.to(dev), b.to(dev), None, dict(stride=1, pad=1, act=F.ACT_NONE))
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(yg.cpu(), 64), yr_b)
+
+
+def test_pixel_shuffle_conv(dev):
+    F = P("functional")
+    n, h, w = 2, 6, 7
+    x = bfr(filler.tensor("x:ps", (n, 64, h, w)))
+    wt = bfr(filler.tensor("w:ps", (256, 64, 3, 3), float(np.sqrt(3.0 / 576))))
+    b = filler.tensor("b:ps", (256,), 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ar = torch.tensor([0.25], requires_grad=True)
+    yr = TF.pixel_shuffle(TF.conv2d(xr, wr, br, padding=1), 2)
+    yr = torch.where(yr >= 0, yr, ar * yr)
+    probe = bfr(filler.tensor("p:ps", tuple(yr.shape)))
+    (yr * probe).sum().backward()
+    xg = to_nhwc(x).to(dev).requires_grad_(True)
+    wg, bg = wt.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    ag = torch.tensor([0.25], device=dev, requires_grad=True)
+    yg = F.ConvAct.apply(xg, wg, bg, ag, dict(stride=1, pad=1, act=F.ACT_PRELU, pixel_shuffle=True))
+    assert tuple(yg.shape) == (n, 2 * h, 2 * w, 64)
+    yg.backward(to_nhwc(probe).to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(yg.detach().cpu(), 64), yr.detach()) < 1.2e-2
+    assert rel_err(from_nhwc(xg.grad.cpu(), 64), xr.grad) < 2.5e-2
+    assert rel_err(wg.grad.cpu(), wr.grad) < 2.5e-2
+    assert rel_err(bg.grad.cpu(), br.grad) < 2.5e-2
+    assert rel_err(ag.grad.cpu(), ar.grad) < 3e-2
+
+
+BN_CASES = [
+    ("g_bn_prelu", 2, 64, 64, 10, 12, 1, 0, "prelu", False, True),
+    ("g_bn_res", 2, 64, 64, 10, 12, 1, 0, "none", True, True),
+    ("d_bn_leaky_s2", 3, 64, 128, 12, 12, 2, 0, "leaky", False, True),
+    ("dip_bn_reflect", 1, 32, 128, 16, 16, 2, 1, "leaky", False, True),
+    ("eval_bn", 2, 64, 64, 8, 8, 1, 0, "prelu", True, False),
+]
+
+
+@pytest.mark.parametrize("case", BN_CASES, ids=[c[0] for c in BN_CASES])
+def test_conv_bn_act(dev, case):
+    F = P("functional")
+    name, n, cin, cout, h, w, stride, pmode, actn, has_res, train = case
+    act = dict(none=F.ACT_NONE, leaky=F.ACT_LEAKY, prelu=F.ACT_PRELU)[actn]
+    slope = 0.2 if actn == "leaky" else 0.25
+    x = bfr(filler.tensor("x:" + name, (n, cin, h, w)))
+    wt = bfr(filler.tensor("w:" + name, (cout, cin, 3, 3), float(np.sqrt(3.0 / (cin * 9)))))
+    b = filler.tensor("b:" + name, (cout,), 0.1)
+    gamma = filler.tensor("g:" + name, (cout,), 0.2, 1.0)
+    beta = filler.tensor("be:" + name, (cout,), 0.1)
+    rm0 = filler.tensor("rm:" + name, (cout,), 0.1)
+    rv0 = filler.tensor("rv:" + name, (cout,), 0.3, 1.0)
+    # reference
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    gr, ber = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ar = torch.tensor([slope], requires_grad=True)
+    rm, rv = rm0.clone(), rv0.clone()
+    yr = TF.conv2d(pad_ref(xr, 1, pmode), wr, br, stride=stride)
+    zr = TF.batch_norm(yr, rm, rv, gr, ber, training=train, momentum=0.1, eps=1e-5)
+    zr = act_ref(F, zr, act, ar if act == F.ACT_PRELU else slope)
+    res = None
+    if has_res:
+        res = bfr(filler.tensor("r:" + name, tuple(zr.shape)))
+        resr = res.clone().requires_grad_(True)
+        zr = zr + resr
+    probe = bfr(filler.tensor("p:" + name, tuple(zr.shape)))
+    (zr * probe).sum().backward()
+    # HIP
+    xg = to_nhwc(x).to(dev).requires_grad_(True)
+    wg, bg = wt.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    gg, beg = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+    ag = torch.tensor([slope], device=dev, requires_grad=True) if act == F.ACT_PRELU else None
+    rmg, rvg = rm0.to(dev), rv0.to(dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    resg = to_nhwc(res).to(dev).requires_grad_(True) if has_res else None
+    cfg = dict(stride=stride, pad=1, pad_mode=pmode, act=act, slope=slope, train=train)
+    zg = F.ConvBNAct.apply(xg, wg, bg, gg, beg, rmg, rvg, nbt, ag, resg, cfg)
+    zg.backward(to_nhwc(probe).to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(zg.detach().cpu(), cout), zr.detach()) < 2e-2
+    if train:
+        assert rel_err(rmg.cpu(), rm) < 2e-3 and rel_err(rvg.cpu(), rv) < 2e-3 and int(nbt) == 1
+    else:
+        assert torch.equal(rmg.cpu(), rm0) and int(nbt) == 0
+    tol = 4e-2
+    assert rel_err(from_nhwc(xg.grad.cpu(), cin), xr.grad) < tol, ("dx", rel_err(from_nhwc(xg.grad.cpu(), cin), xr.grad))
+    assert rel_err(wg.grad.cpu(), wr.grad) < tol, ("dw", rel_err(wg.grad.cpu(), wr.grad))
+    assert rel_err(gg.grad.cpu(), gr.grad) < tol, ("dgamma", rel_err(gg.grad.cpu(), gr.grad))
+    assert rel_err(beg.grad.cpu(), ber.grad) < tol, ("dbeta", rel_err(beg.grad.cpu(), ber.grad))
+    if ag is not None:
+        assert rel_err(ag.grad.cpu(), ar.grad) < tol
+    if has_res:
+        assert rel_err(from_nhwc(resg.grad.cpu(), cout), resr.grad) < 1e-6
+    if not train:
+        assert rel_err(bg.grad.cpu(), br.grad) < tol
+
+
+@pytest.mark.parametrize("actn,cout", [("tanh", 3), ("sigmoid", 3), ("none", 5)])
+def test_conv_out_nchw(dev, actn, cout):
+    F = P("functional")
+    act = dict(tanh=F.ACT_TANH, sigmoid=F.ACT_SIGMOID, none=F.ACT_NONE)[actn]
+    k, pad = (9, 4) if actn == "tanh" else (1, 0)
+    x = bfr(filler.tensor("x:o" + actn, (2, 64, 9, 11)))
+    wt = bfr(filler.tensor("w:o" + actn, (cout, 64, k, k), float(np.sqrt(3.0 / (64 * k * k)))))
+    b = filler.tensor("b:o" + actn, (cout,), 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = act_ref(F, TF.conv2d(xr, wr, br, padding=pad), act, 0.0)
+    probe = filler.tensor("p:o" + actn, tuple(yr.shape))
+    (yr * probe).sum().backward()
+    xg = to_nhwc(x).to(dev).requires_grad_(True)
+    wg, bg = wt.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    yg = F.ConvOutNCHW.apply(xg, wg, bg, dict(stride=1, pad=pad, act=act))
+    assert yg.dtype == torch.float32 and tuple(yg.shape) == tuple(yr.shape)
+    yg.backward(probe.to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(yg.detach().cpu(), yr.detach()) < 2e-5      # fp32 output of fp32 accumulation
+    assert rel_err(from_nhwc(xg.grad.cpu(), 64), xr.grad) < 2.5e-2
+    assert rel_err(wg.grad.cpu(), wr.grad) < 2.5e-2
+    assert rel_err(bg.grad.cpu(), br.grad) < 2.5e-2
+
+
+def test_layout_roundtrip(dev):
+    F = P("functional")
+    x = filler.tensor("x:lay", (2, 5, 6, 7)).requires_grad_(True)
+    xg = x.detach().to(dev).requires_grad_(True)
+    y = F.ToNHWC.apply(xg, torch.bfloat16)
+    assert tuple(y.shape) == (2, 6, 7, 8)
+    assert torch.equal(y[..., :5].cpu().float(), bfr(x.detach()).permute(0, 2, 3, 1))
+    assert float(y[..., 5:].float().abs().max()) == 0.0
+    z = F.ToNCHW.apply(y, 5)
+    assert torch.equal(z.cpu(), bfr(x.detach()))
+    z.backward(torch.ones_like(z))
+    assert torch.equal(xg.grad.cpu(), torch.ones(2, 5, 6, 7))
+
+
+def test_losses_and_adam(dev):
+    F = P("functional")
+    optim = P("optim")
+    a = filler.tensor("l:a", (3, 3, 8, 8))
+    b = filler.tensor("l:b", (3, 3, 8, 8))
+    for mode, fn in ((0, lambda p, q: (p - q).abs().mean()), (1, lambda p, q: ((p - q) ** 2).mean())):
+        ar = a.clone().requires_grad_(True)
+        lr_ = fn(ar, b)
+        lr_.backward()
+        ag = a.to(dev).requires_grad_(True)
+        lg = F.DiffLoss.apply(ag, b.to(dev), mode)
+        lg.backward()
+        assert abs(lg.item() - lr_.item()) < 1e-6 * max(1, abs(lr_.item()))
+        assert rel_err(ag.grad.cpu(), ar.grad) < 1e-6
+    p = (filler.tensor("l:p", (7, 1), 0.45, 0.5)).clamp(1e-4, 1 - 1e-4)
+    p[0, 0] = 0.0          # exercises the -100 clamp of nn.BCELoss
+    p[1, 0] = 1.0
+    for target in (0.0, 1.0):
+        pr = p.clone().requires_grad_(True)
+        lref = TF.binary_cross_entropy(pr, torch.full_like(pr, target))
+        lref.backward()
+        pg = p.to(dev).requires_grad_(True)
+        lg = F.bce_const(pg, target)
+        lg.backward()
+        assert abs(lg.item() - lref.item()) < 1e-5 * max(1, abs(lref.item())), (lg.item(), lref.item())
+        fin = torch.isfinite(pr.grad)
+        assert rel_err(pg.grad.cpu()[fin], pr.grad[fin]) < 1e-5
+    # Adam: 3 steps against torch.optim.Adam
+    w0 = filler.tensor("adam:w", (37, 5))
+    wr = w0.clone().requires_grad_(True)
+    wg = w0.to(dev).requires_grad_(True)
+    oref = torch.optim.Adam([wr], lr=1e-2)
+    og = optim.FusedAdam([wg], lr=1e-2)
+    for it in range(3):
+        g = filler.tensor(f"adam:g{it}", (37, 5))
+        wr.grad = g.clone()
+        wg.grad = g.to(dev)
+        oref.step()
+        og.step()
+    torch.cuda.synchronize()
+    assert rel_err(wg.detach().cpu(), wr.detach()) < 1e-6
