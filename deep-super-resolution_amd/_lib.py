@@ -61,6 +61,23 @@ SIGNATURES = {
     "dsr_pw_bce_const": (_I, [_P, _I, _F, _P, _P, _I, _P]),
     "dsr_pw_adam": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P, _P]),
     "dsr_pw_incr": (_I, [_P, _P]),
+    "dsr_cast16": (_I, [_I, _P, _P, _Z, _P]),
+    "dsr_flatten": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dsr_linear_fwd_workspace": (_Z, [_I, _Z, _I]),
+    "dsr_linear_fwd": (_I, [_I, _P, _P, _P, _I, _F, _P, _I, _Z, _I, _P, _Z, _P]),
+    "dsr_linear_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _Z, _P]),
+    "dsr_linear_wgrad": (_I, [_I, _P, _P, _P, _I, _I, _Z, _P]),
+    "dsr_dense2_fwd": (_I, [_P, _P, _P, _I, _I, _P, _P]),
+    "dsr_dense2_bwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
+    "dsr_maxpool2_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
+    "dsr_maxpool2_bwd": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dsr_bilinear2x_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
+    "dsr_bilinear2x_bwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
+    "dsr_resize_norm_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "dsr_resize_norm_bwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "dsr_box_copy": (_I, [_P, _P] + [_I] * 16 + [_P]),
+    "dsr_downsample_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dsr_downsample_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

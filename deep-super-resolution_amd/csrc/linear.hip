@@ -1,0 +1,382 @@
+// The discriminator's dense head on gfx950 (models/GAN/discriminator.py:37-45, 65-72):
+//   flatten (C,H,W order, :65) -> Linear(K, 1024) -> LeakyReLU(0.2) -> Linear(1024, 1) -> Sigmoid.
+// dense1 is a batch-32 x (K up to 524,288) x 1024 problem: every kernel here is bound by
+// streaming the K x 1024 weight (or its gradient) once through HBM, so the design goal is
+// full-line, fully coalesced 16-byte accesses with many bytes in flight; MFMA 16x16x32 is used only
+// because it is the cheapest way to do the (tiny) arithmetic at that rate.
+//
+//   linear_fwd   : split-K partial slabs [S][B][O] (deterministic), W rows streamed straight to VGPRs
+//   linear_dgrad : dx[b][k] = sum_o dy[b][o] W[o][k]  -- W tile through LDS, ds_read_b64_tr_b16 transposes
+//   linear_wgrad : dW[o][k] = sum_b dy[b][o] x[b][k]  -- batch is the MFMA K; 16-byte fp32 stores
+#include "../../include/dsr_hip.h"
+#include "dsr_common.h"
+#include "dsr_kernels.h"
+
+// ------------------------------------------------------------------ fp32 -> 16-bit shadow copy of a weight
+template <int DT>
+__global__ void cast16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n8) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n8; i += stride) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * i];
+    const float4 b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    reinterpret_cast<U4*>(dst)[i] = pack8<DT>(f);
+  }
+}
+
+// ------------------------------------------------------------------ flatten NHWC -> [B][C*HW] (CHW order) and friends
+// mode 0: flat[b][c*HW+p] = act[b][p][c]        (forward input of dense1)
+// mode 1: flatT[c*HW+p][b] = act[b][p][c]       (batch-minor copy for wgrad; Bp columns, zero padded)
+// mode 2: act[b][p][c] = flat[b][c*HW+p]        (gradient back to NHWC)
+template <int DT>
+__global__ void flatten_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst, int B, int HW,
+                               int C, int Cp, int Bp, int mode) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t K = (size_t)C * HW;
+  if (mode == 0) {
+    if (idx >= (size_t)B * K) return;
+    int b = (int)(idx / K);
+    size_t k = idx % K;
+    int c = (int)(k / HW), p = (int)(k % HW);
+    dst[idx] = src[((size_t)b * HW + p) * Cp + c];
+  } else if (mode == 1) {
+    if (idx >= K * Bp) return;
+    int b = (int)(idx % Bp);
+    size_t k = idx / Bp;
+    int c = (int)(k / HW), p = (int)(k % HW);
+    dst[idx] = b < B ? src[((size_t)b * HW + p) * Cp + c] : (unsigned short)0;
+  } else {
+    if (idx >= (size_t)B * HW * Cp) return;
+    int c = (int)(idx % Cp);
+    size_t bp = idx / Cp;
+    int p = (int)(bp % HW), b = (int)(bp / HW);
+    dst[idx] = c < C ? src[(size_t)b * K + (size_t)c * HW + p] : (unsigned short)0;
+  }
+}
+
+// ------------------------------------------------------------------ forward: split-K partials
+template <int DT, int MT>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const unsigned short* __restrict__ x,
+                                                         const unsigned short* __restrict__ w,
+                                                         float* __restrict__ partial, int B, size_t K, int O,
+                                                         size_t kchunk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int o = blockIdx.x * 64 + wave * 16 + r;
+  const bool ook = o < O;
+  const size_t k0 = (size_t)blockIdx.y * kchunk;
+  size_t k1 = k0 + kchunk;
+  if (k1 > K) k1 = K;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned short* wrow = w + (size_t)(ook ? o : 0) * K;
+  for (size_t k = k0; k < k1; k += 128) {
+    U4 fb[4], fa[4][MT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t kk = k + 32 * u + 8 * g;
+      const bool kok = kk < k1;
+      fb[u] = load16_or_zero(wrow, kk, kok && ook);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int b = 16 * m + r;
+        fa[u][m] = load16_or_zero(x, (size_t)b * K + kk, kok && b < B);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = mfma16<DT>(fa[u][m], fb[u], acc[m]);
+  }
+  float* P = partial + (size_t)blockIdx.y * B * O;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int b = 16 * m + 4 * g + j;
+      if (b < B && ook) P[(size_t)b * O + o] = acc[m][j];
+    }
+}
+
+// out[b][o] = act(sum_s partial[s][b][o] + bias[o])   (fp32)
+__global__ void linear_reduce_kernel(const float* __restrict__ partial, int S, int B, int O,
+                                     const float* __restrict__ bias, int act, float slope, float* __restrict__ out) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * O) return;
+  double s = 0.0;
+  for (int z = 0; z < S; ++z) s += (double)partial[(size_t)z * B * O + idx];
+  float v = (float)s + (bias ? bias[idx % O] : 0.f);
+  out[idx] = act_apply(act, v, slope);
+}
+
+// ------------------------------------------------------------------ dgrad: dx[b][k] = sum_o dy[b][o] W[o][k]
+__device__ __forceinline__ s16x4 lds_tr_read16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+template <int DT, int MT>
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(const unsigned short* __restrict__ dy,
+                                                           const unsigned short* __restrict__ w,
+                                                           unsigned short* __restrict__ dx, int B, int O, size_t K) {
+  __shared__ __attribute__((aligned(16))) unsigned char sW[64 * 128];   // [64 o][64 k] 16-bit, XOR-swizzled chunks
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  const size_t kb = (size_t)blockIdx.x * 64;
+  const int c = tid & 7, rr = tid >> 3;   // loader: chunk c (8 k), rows rr and rr+32
+  const bool kok = (kb + c * 8) < K;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int q = l16 >> 2, cc = 4 * (l16 & 3);
+  const int col = wave * 16 + cc;                    // first of this lane's 4 k-columns inside the tile
+  const int chunk = col >> 3, within = (col & 7) * 2;
+  for (int o0 = 0; o0 < O; o0 += 64) {
+    U4 v0 = load16_or_zero(w, (size_t)(o0 + rr) * K + kb + c * 8, kok && (o0 + rr) < O);
+    U4 v1 = load16_or_zero(w, (size_t)(o0 + rr + 32) * K + kb + c * 8, kok && (o0 + rr + 32) < O);
+    __syncthreads();
+    *reinterpret_cast<U4*>(sW + rr * 128 + ((c ^ (rr & 7)) << 4)) = v0;
+    *reinterpret_cast<U4*>(sW + (rr + 32) * 128 + ((c ^ ((rr + 32) & 7)) << 4)) = v1;
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int p1 = 32 * sub + 4 * g + q, p2 = p1 + 16;
+      s16x4 b1 = lds_tr_read16(sW + p1 * 128 + ((chunk ^ (p1 & 7)) << 4) + within);
+      s16x4 b2 = lds_tr_read16(sW + p2 * 128 + ((chunk ^ (p2 & 7)) << 4) + within);
+      U4 fb = __builtin_bit_cast(U4, __builtin_shufflevector(b1, b2, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int b = 16 * m + l16;
+        const int oa = o0 + 32 * sub + 4 * g;   // this lane's k-slots: o = oa..oa+3 and oa+16..oa+19
+        const bool ok = b < B;
+        const unsigned short* row = dy + (size_t)(ok ? b : 0) * O;
+        uint2 a1 = *reinterpret_cast<const uint2*>(row + (oa < O ? oa : 0));
+        uint2 a2 = *reinterpret_cast<const uint2*>(row + (oa + 16 < O ? oa + 16 : 0));
+        U4 fa;
+        fa.x = (ok && oa < O) ? a1.x : 0u;
+        fa.y = (ok && oa < O) ? a1.y : 0u;
+        fa.z = (ok && oa + 16 < O) ? a2.x : 0u;
+        fa.w = (ok && oa + 16 < O) ? a2.y : 0u;
+        acc[m] = mfma16<DT>(fa, fb, acc[m]);
+      }
+    }
+  }
+  const size_t k = kb + wave * 16 + l16;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int b = 16 * m + 4 * g + j;
+      if (b < B && k < K) dx[(size_t)b * K + k] = f2h<DT>(acc[m][j]);
+    }
+}
+
+// ------------------------------------------------------------------ wgrad: dW[o][k] = sum_b dyT[o][b] xT[k][b]
+// D[m = k][n = o]: a lane ends up with 4 consecutive k of one o -> one 16-byte fp32 store.
+template <int DT, int BP>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const unsigned short* __restrict__ dyT,
+                                                           const unsigned short* __restrict__ xT,
+                                                           float* __restrict__ dw, int O, size_t K, int ktiles_per_block) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int o = blockIdx.y * 64 + wave * 16 + r;
+  const bool ook = o < O;
+  constexpr int KS = BP / 32;
+  U4 fb[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) fb[s] = load16_or_zero(dyT, (size_t)o * BP + 32 * s + 8 * g, ook);
+  const size_t kt0 = (size_t)blockIdx.x * ktiles_per_block;
+  for (int t = 0; t < ktiles_per_block; ++t) {
+    const size_t kbase = (kt0 + t) * 16;
+    if (kbase >= K) break;
+    const size_t krow = kbase + r;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      U4 fa = load16_or_zero(xT, krow * BP + 32 * s + 8 * g, krow < K);
+      acc = mfma16<DT>(fa, fb[s], acc);
+    }
+    const size_t k = kbase + 4 * g;   // rows 4g..4g+3 of the tile = 4 consecutive k, column r = output o
+    if (ook && k + 3 < K) {
+      *reinterpret_cast<float4*>(dw + (size_t)o * K + k) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else if (ook) {
+      for (int j = 0; j < 4; ++j)
+        if (k + j < K) dw[(size_t)o * K + k + j] = acc[j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ the small fp32 tail: Linear(K1,1) + Sigmoid and its backward
+// out[b] = sigmoid(sum_k h[b][k] w2[k] + b2)
+__global__ __launch_bounds__(256) void dense2_fwd_kernel(const float* __restrict__ h, const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, int K1, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K1; k += 256) s += h[(size_t)b * K1 + k] * w2[k];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = red[0] + red[1] + red[2] + red[3] + b2[0];
+    out[b] = 1.f / (1.f + expf(-v));
+  }
+}
+
+// one thread per hidden unit k: everything the head's backward needs besides the two big GEMMs
+//   dz[b]   = dout[b] * out[b] * (1 - out[b])
+//   dw2[k]  = sum_b dz[b] * h[b][k];  db2 = sum_b dz[b]
+//   dh[b][k]= dz[b] * w2[k] * leaky'(h[b][k])     (h is the post-LeakyReLU activation; slope > 0)
+//   db1[k]  = sum_b dh[b][k];  dy16[b][k] and dyT16[k][b] = 16-bit copies of dh for the MFMA kernels
+template <int DT>
+__global__ void dense2_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                  const float* __restrict__ h, const float* __restrict__ w2, int B, int K1, int BP,
+                                  float slope, float* __restrict__ dw2, float* __restrict__ db2,
+                                  float* __restrict__ db1, unsigned short* __restrict__ dy16,
+                                  unsigned short* __restrict__ dyT16) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K1) return;
+  float sw = 0.f, sb1 = 0.f, sz = 0.f;
+  const float wk = w2[k];
+  for (int b = 0; b < BP; ++b) {
+    float d = 0.f;
+    if (b < B) {
+      const float o = out[b];
+      const float dz = dout[b] * o * (1.f - o);
+      const float hv = h[(size_t)b * K1 + k];
+      sz += dz;
+      sw += dz * hv;
+      d = dz * wk * (hv >= 0.f ? 1.f : slope);
+      sb1 += d;
+      dy16[(size_t)b * K1 + k] = f2h<DT>(d);
+    }
+    dyT16[(size_t)k * BP + b] = f2h<DT>(d);
+  }
+  dw2[k] = sw;
+  db1[k] = sb1;
+  if (k == 0) db2[0] = sz;
+}
+
+// ================================================================== C ABI
+extern "C" int dsr_cast16(int dtype, const float* src, void* dst, size_t n, dsr_stream_t st) {
+  if (n % 8) return dsr_fail(DSR_E_ARG, "cast16: element count %zu not a multiple of 8", n);
+  size_t n8 = n / 8;
+  unsigned blocks = (unsigned)((n8 + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == DSR_BF16)
+    hipLaunchKernelGGL((cast16_kernel<DSR_DTYPE_BF16>), dim3(blocks), dim3(256), 0, st, src, (unsigned short*)dst, n8);
+  else
+    hipLaunchKernelGGL((cast16_kernel<DSR_DTYPE_F16>), dim3(blocks), dim3(256), 0, st, src, (unsigned short*)dst, n8);
+  return dsr_launch_status("dsr_cast16");
+}
+
+extern "C" int dsr_flatten(int dtype, const void* src, void* dst, int B, int HW, int C, int Cp, int Bp, int mode,
+                           dsr_stream_t st) {
+  size_t total = mode == 0 ? (size_t)B * C * HW : (mode == 1 ? (size_t)C * HW * Bp : (size_t)B * HW * Cp);
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dtype == DSR_BF16)
+    hipLaunchKernelGGL((flatten_kernel<DSR_DTYPE_BF16>), grid, block, 0, st, (const unsigned short*)src,
+                       (unsigned short*)dst, B, HW, C, Cp, Bp, mode);
+  else
+    hipLaunchKernelGGL((flatten_kernel<DSR_DTYPE_F16>), grid, block, 0, st, (const unsigned short*)src,
+                       (unsigned short*)dst, B, HW, C, Cp, Bp, mode);
+  return dsr_launch_status("dsr_flatten");
+}
+
+static int linear_splits(size_t K, int O, size_t* kchunk) {
+  long long otiles = (O + 63) / 64;
+  long long want = (2048 + otiles - 1) / otiles;
+  long long maxs = (long long)((K + 1023) / 1024);
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  size_t ch = (K + want - 1) / want;
+  ch = (ch + 127) / 128 * 128;
+  *kchunk = ch;
+  return (int)((K + ch - 1) / ch);
+}
+
+extern "C" size_t dsr_linear_fwd_workspace(int B, size_t K, int O) {
+  size_t ch;
+  int S = linear_splits(K, O, &ch);
+  return (size_t)S * B * O * sizeof(float);
+}
+
+extern "C" int dsr_linear_fwd(int dtype, const void* x, const void* w16, const float* bias, int act, float slope,
+                              float* out, int B, size_t K, int O, void* workspace, size_t ws_bytes, dsr_stream_t st) {
+  if (B < 1 || B > 64) return dsr_fail(DSR_E_UNSUPPORTED, "linear: batch %d outside 1..64", B);
+  if (K % 8) return dsr_fail(DSR_E_ARG, "linear: K %% 8 != 0");
+  size_t ch;
+  int S = linear_splits(K, O, &ch);
+  if (!workspace || ws_bytes < (size_t)S * B * O * sizeof(float)) return dsr_fail(DSR_E_WORKSPACE, "linear_fwd: workspace");
+  dim3 grid((O + 63) / 64, S), block(256);
+  const unsigned short* X = (const unsigned short*)x;
+  const unsigned short* W = (const unsigned short*)w16;
+  float* P = (float*)workspace;
+#define LAUNCH_FWD(DTV, MTV) \
+  hipLaunchKernelGGL((linear_fwd_kernel<DTV, MTV>), grid, block, 0, st, X, W, P, B, K, O, ch)
+  if (dtype == DSR_BF16) {
+    if (B <= 32) LAUNCH_FWD(DSR_DTYPE_BF16, 2); else LAUNCH_FWD(DSR_DTYPE_BF16, 4);
+  } else {
+    if (B <= 32) LAUNCH_FWD(DSR_DTYPE_F16, 2); else LAUNCH_FWD(DSR_DTYPE_F16, 4);
+  }
+#undef LAUNCH_FWD
+  hipLaunchKernelGGL(linear_reduce_kernel, dim3((B * O + 255) / 256), dim3(256), 0, st, P, S, B, O, bias, act, slope, out);
+  return dsr_launch_status("dsr_linear_fwd");
+}
+
+extern "C" int dsr_linear_dgrad(int dtype, const void* dy16, const void* w16, void* dx, int B, int O, size_t K,
+                                dsr_stream_t st) {
+  if (B < 1 || B > 64) return dsr_fail(DSR_E_UNSUPPORTED, "linear: batch %d outside 1..64", B);
+  if (K % 8 || O % 4) return dsr_fail(DSR_E_ARG, "linear_dgrad: K %% 8 or O %% 4");
+  dim3 grid((unsigned)((K + 63) / 64)), block(256);
+  const unsigned short* DY = (const unsigned short*)dy16;
+  const unsigned short* W = (const unsigned short*)w16;
+  unsigned short* DX = (unsigned short*)dx;
+#define LAUNCH_DG(DTV, MTV) hipLaunchKernelGGL((linear_dgrad_kernel<DTV, MTV>), grid, block, 0, st, DY, W, DX, B, O, K)
+  if (dtype == DSR_BF16) {
+    if (B <= 32) LAUNCH_DG(DSR_DTYPE_BF16, 2); else LAUNCH_DG(DSR_DTYPE_BF16, 4);
+  } else {
+    if (B <= 32) LAUNCH_DG(DSR_DTYPE_F16, 2); else LAUNCH_DG(DSR_DTYPE_F16, 4);
+  }
+#undef LAUNCH_DG
+  return dsr_launch_status("dsr_linear_dgrad");
+}
+
+extern "C" int dsr_linear_wgrad(int dtype, const void* dyT16, const void* xT16, float* dw, int Bp, int O, size_t K,
+                                dsr_stream_t st) {
+  if (Bp != 32 && Bp != 64) return dsr_fail(DSR_E_UNSUPPORTED, "linear_wgrad: padded batch must be 32 or 64");
+  if (K % 4) return dsr_fail(DSR_E_ARG, "linear_wgrad: K %% 4");
+  const int tpb = 64;   // 16-wide k tiles per block -> 1024 k per block
+  size_t ktiles = (K + 15) / 16;
+  dim3 grid((unsigned)((ktiles + tpb - 1) / tpb), (O + 63) / 64), block(256);
+  const unsigned short* DYT = (const unsigned short*)dyT16;
+  const unsigned short* XT = (const unsigned short*)xT16;
+#define LAUNCH_WG(DTV, BPV) hipLaunchKernelGGL((linear_wgrad_kernel<DTV, BPV>), grid, block, 0, st, DYT, XT, dw, O, K, tpb)
+  if (dtype == DSR_BF16) {
+    if (Bp == 32) LAUNCH_WG(DSR_DTYPE_BF16, 32); else LAUNCH_WG(DSR_DTYPE_BF16, 64);
+  } else {
+    if (Bp == 32) LAUNCH_WG(DSR_DTYPE_F16, 32); else LAUNCH_WG(DSR_DTYPE_F16, 64);
+  }
+#undef LAUNCH_WG
+  return dsr_launch_status("dsr_linear_wgrad");
+}
+
+extern "C" int dsr_dense2_fwd(const float* h, const float* w2, const float* b2, int B, int K1, float* out,
+                              dsr_stream_t st) {
+  hipLaunchKernelGGL(dense2_fwd_kernel, dim3(B), dim3(256), 0, st, h, w2, b2, K1, out);
+  return dsr_launch_status("dsr_dense2_fwd");
+}
+
+extern "C" int dsr_dense2_bwd(int dtype, const float* dout, const float* out, const float* h, const float* w2, int B,
+                              int K1, int Bp, float slope, float* dw2, float* db2, float* db1, void* dy16, void* dyT16,
+                              dsr_stream_t st) {
+  dim3 grid((K1 + 127) / 128), block(128);
+  if (dtype == DSR_BF16)
+    hipLaunchKernelGGL((dense2_bwd_kernel<DSR_DTYPE_BF16>), grid, block, 0, st, dout, out, h, w2, B, K1, Bp, slope, dw2,
+                       db2, db1, (unsigned short*)dy16, (unsigned short*)dyT16);
+  else
+    hipLaunchKernelGGL((dense2_bwd_kernel<DSR_DTYPE_F16>), grid, block, 0, st, dout, out, h, w2, B, K1, Bp, slope, dw2,
+                       db2, db1, (unsigned short*)dy16, (unsigned short*)dyT16);
+  return dsr_launch_status("dsr_dense2_bwd");
+}

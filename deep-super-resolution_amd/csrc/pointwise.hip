@@ -519,10 +519,8 @@ __global__ void bce_const_kernel(const float* __restrict__ p, int n, float targe
     float l1 = fmaxf(logf(v), -100.f), l0 = fmaxf(logf(1.f - v), -100.f);
     s += -(target * l1 + (1.f - target) * l0);
     if (grad) {
-      // d/dv of the clamped logs: zero where the clamp is active
-      float g1 = (logf(v) > -100.f) ? 1.f / v : 0.f;
-      float g0 = (logf(1.f - v) > -100.f) ? -1.f / (1.f - v) : 0.f;
-      grad[i] = -(target * g1 + (1.f - target) * g0) / (float)n;
+      // torch's binary_cross_entropy backward: (x - t) / max((1 - x) * x, 1e-12), mean reduction
+      grad[i] = (v - target) / fmaxf((1.f - v) * v, 1e-12f) / (float)n;
     }
   }
   s = wave_sum(s);
@@ -605,6 +603,7 @@ extern "C" int dsr_pw_bn_eval_affine(const float* gamma, const float* beta, cons
                            int Cp, float* scale, float* shift, float* mean, float* rstd, hipStream_t st) {
   hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(nblk(Cp, 128)), dim3(128), 0, st, gamma, beta, rm, rv, eps, C, Cp,
                      scale, shift, mean, rstd);
+  return dsr_launch_status("dsr_pw_bn_eval_affine");
 }
 extern "C" int dsr_pw_reduce_blocks(size_t P, int* rows_per_block) {
   // enough blocks to fill 256 CUs a few times over, at least 64 rows each
@@ -613,7 +612,6 @@ extern "C" int dsr_pw_reduce_blocks(size_t P, int* rows_per_block) {
   if (rpb < 64) rpb = 64;
   *rows_per_block = (int)rpb;
   return (int)((P + rpb - 1) / rpb);
-  return dsr_launch_status("dsr_pw_bn_eval_affine");
 }
 extern "C" int dsr_pw_channel_stats(int dtype, const void* x, size_t P, int Cp, int blocks, int rpb, float* partial,
                           hipStream_t st) {

@@ -428,3 +428,285 @@ class BCEConst(torch.autograd.Function):
 
 def bce_const(p, target):
     return BCEConst.apply(p, target)
+
+
+# ----------------------------------------------------------------------------- discriminator dense head
+_shadow_cache = {}
+
+
+def shadow16(weight, dtype):
+    """16-bit copy of an fp32 matrix in its own layout, refreshed when the parameter changes."""
+    key = (id(weight), dtype)
+    ver = _version(weight)
+    hit = _shadow_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    w = weight.detach().contiguous()
+    out = hit[1] if hit is not None and hit[1].numel() == w.numel() else torch.empty(w.shape, dtype=dtype, device=w.device)
+    check(_lib.lib().dsr_cast16(_dt(out), _ptr(w), _ptr(out), w.numel(), _stream()))
+    _shadow_cache[key] = (ver, out)
+    return out
+
+
+class DenseHead(torch.autograd.Function):
+    """sigmoid(Linear(1024,1)(leaky_relu(Linear(K,1024)(flatten_CHW(x)), 0.2)))  -- discriminator.py:65-72.
+
+    x is the NHWC 16-bit output of the last conv block; the C,H,W flatten order of ``x.view(N,-1)`` on an
+    NCHW tensor (:65) is reproduced by a small transposing copy, so dense1.weight keeps the reference layout."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, c):
+        _need_gpu(x)
+        lib = _lib.lib()
+        x = x.contiguous()
+        n, h, w, cp = x.shape
+        hw = h * w
+        k = c * hw
+        o = w1.shape[0]
+        if w1.shape[1] != k:
+            raise RuntimeError(f"dense1 expects {w1.shape[1]} features, the conv stack produced {k}")   # torch raises too
+        dev = x.device
+        st = _stream()
+        flat = torch.empty((n, k), dtype=x.dtype, device=dev)
+        check(lib.dsr_flatten(_dt(x), _ptr(x), _ptr(flat), n, hw, c, cp, 0, 0, st))
+        w16 = shadow16(w1, x.dtype)
+        wsz = lib.dsr_linear_fwd_workspace(n, k, o)
+        ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+        h1 = torch.empty((n, o), dtype=torch.float32, device=dev)
+        check(lib.dsr_linear_fwd(_dt(x), _ptr(flat), _ptr(w16), _ptr(b1), ACT_LEAKY, 0.2, _ptr(h1), n, k, o, _ptr(ws),
+                                 wsz, st))
+        out = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        check(lib.dsr_dense2_fwd(_ptr(h1), _ptr(w2), _ptr(b2), n, o, _ptr(out), st))
+        ctx.c = c
+        ctx.save_for_backward(x, h1, out, w16, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h1, out, w16, w2 = ctx.saved_tensors
+        lib = _lib.lib()
+        n, h, w, cp = x.shape
+        hw, c = h * w, ctx.c
+        k = c * hw
+        o = h1.shape[1]
+        dev = x.device
+        st = _stream()
+        bp = 32 if n <= 32 else 64
+        dout = dout.contiguous().float()
+        dw2 = torch.empty((1, o), dtype=torch.float32, device=dev)
+        db2 = torch.empty(1, dtype=torch.float32, device=dev)
+        db1 = torch.empty(o, dtype=torch.float32, device=dev)
+        dy16 = torch.empty((n, o), dtype=x.dtype, device=dev)
+        dyt16 = torch.empty((o, bp), dtype=x.dtype, device=dev)
+        check(lib.dsr_dense2_bwd(_dt(x), _ptr(dout), _ptr(out), _ptr(h1), _ptr(w2), n, o, bp, 0.2, _ptr(dw2), _ptr(db2),
+                                 _ptr(db1), _ptr(dy16), _ptr(dyt16), st))
+        dx = dw1 = None
+        if ctx.needs_input_grad[0]:
+            dflat = torch.empty((n, k), dtype=x.dtype, device=dev)
+            check(lib.dsr_linear_dgrad(_dt(x), _ptr(dy16), _ptr(w16), _ptr(dflat), n, o, k, st))
+            dx = torch.empty_like(x)
+            check(lib.dsr_flatten(_dt(x), _ptr(dflat), _ptr(dx), n, hw, c, cp, 0, 2, st))
+        if ctx.needs_input_grad[1]:
+            xt = torch.empty((k, bp), dtype=x.dtype, device=dev)
+            check(lib.dsr_flatten(_dt(x), _ptr(x), _ptr(xt), n, hw, c, cp, bp, 1, st))
+            dw1 = torch.empty((o, k), dtype=torch.float32, device=dev)
+            check(lib.dsr_linear_wgrad(_dt(x), _ptr(dyt16), _ptr(xt), _ptr(dw1), bp, o, k, st))
+        return dx, dw1, db1, dw2, db2, None
+
+
+# ----------------------------------------------------------------------------- pooling / resampling
+class MaxPool2(torch.autograd.Function):
+    """nn.MaxPool2d(2, 2) on NHWC (VGG19 trunk, utils/GAN.py:24-47)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        n, h, w, cp = x.shape
+        y = torch.empty((n, h // 2, w // 2, cp), dtype=x.dtype, device=x.device)
+        check(_lib.lib().dsr_maxpool2_fwd(_dt(x), _ptr(x), _ptr(y), n, h, w, cp, _stream()))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, h, w, cp = x.shape
+        dx = torch.empty_like(x)
+        check(_lib.lib().dsr_maxpool2_bwd(_dt(x), _ptr(x), _ptr(dy.contiguous()), _ptr(dx), n, h, w, cp, _stream()))
+        return dx
+
+
+class Bilinear2x(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2, mode='bilinear') (align_corners=False) on NHWC (models/DIP/skip.py:77)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        n, h, w, cp = x.shape
+        y = torch.empty((n, 2 * h, 2 * w, cp), dtype=x.dtype, device=x.device)
+        check(_lib.lib().dsr_bilinear2x_fwd(_dt(x), _ptr(x), _ptr(y), n, h, w, cp, _stream()))
+        ctx.shape = (n, h, w, cp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, cp = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((n, h, w, cp), dtype=dy.dtype, device=dy.device)
+        check(_lib.lib().dsr_bilinear2x_bwd(_dt(dy), _ptr(dy), _ptr(dx), n, h, w, cp, _stream()))
+        return dx
+
+
+class ResizeNorm(torch.autograd.Function):
+    """torchvision ImageClassification preset on an fp32 NCHW batch -> NHWC 16-bit [N, crop, crop, 8].
+
+    ``tab`` is a ResampleTables object (utils/GAN.py mirror) holding the device-resident forward and
+    transposed weight tables of the separable antialiased resize + centre crop."""
+
+    @staticmethod
+    def forward(ctx, img, tab, dtype):
+        _need_gpu(img)
+        img = img.contiguous().float()
+        n, c, h, w = img.shape
+        assert (h, w) == (tab.in_h, tab.in_w), ((h, w), (tab.in_h, tab.in_w))
+        out = torch.empty((n, tab.out_h, tab.out_w, 8), dtype=dtype, device=img.device)
+        check(_lib.lib().dsr_resize_norm_fwd(_dt(out), _ptr(img), _ptr(out), n, c, h, w, tab.out_h, tab.out_w,
+                                             _ptr(tab.ys), _ptr(tab.yc), _ptr(tab.yw), _ptr(tab.xs), _ptr(tab.xc),
+                                             _ptr(tab.xw), tab.kt, tab.mean_c, tab.std_c, _stream()))
+        ctx.tab, ctx.shape = tab, (n, c, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tab = ctx.tab
+        n, c, h, w = ctx.shape
+        dout = dout.contiguous()
+        dimg = torch.empty((n, c, h, w), dtype=torch.float32, device=dout.device)
+        check(_lib.lib().dsr_resize_norm_bwd(_dt(dout), _ptr(dout), _ptr(dimg), n, c, h, w, tab.out_h, tab.out_w,
+                                             _ptr(tab.tys), _ptr(tab.tyc), _ptr(tab.tyw), _ptr(tab.txs), _ptr(tab.txc),
+                                             _ptr(tab.txw), tab.kt, tab.std_c, _stream()))
+        return dimg, None, None
+
+
+def _box_copy(src, dst, n, bh, bw, c, sy0, sx0, cs0, dy0, dx0, cd0):
+    check(_lib.lib().dsr_box_copy(_ptr(src), _ptr(dst), n, bh, bw, c, src.shape[1], src.shape[2], src.shape[3], sy0, sx0,
+                                  cs0, dst.shape[1], dst.shape[2], dst.shape[3], dy0, dx0, cd0, _stream()))
+
+
+class ConcatCrop(torch.autograd.Function):
+    """torch.cat([a, b], dim=1) after centre-cropping both to the smaller H, W (models/DIP/utils.py:18-38)."""
+
+    @staticmethod
+    def forward(ctx, a, b, ca, cb):
+        a, b = a.contiguous(), b.contiguous()
+        n = a.shape[0]
+        h, w = min(a.shape[1], b.shape[1]), min(a.shape[2], b.shape[2])
+        out = torch.zeros((n, h, w, r8(ca + cb)), dtype=a.dtype, device=a.device)
+        offs = []
+        c0 = 0
+        for t, c in ((a, ca), (b, cb)):
+            d2, d3 = (t.shape[1] - h) // 2, (t.shape[2] - w) // 2
+            _box_copy(t, out, n, h, w, c, d2, d3, 0, 0, 0, c0)
+            offs.append((d2, d3, c0, c, tuple(t.shape)))
+            c0 += c
+        ctx.offs, ctx.hw = offs, (h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        n = dout.shape[0]
+        h, w = ctx.hw
+        grads = []
+        for d2, d3, c0, c, shape in ctx.offs:
+            g = torch.zeros(shape, dtype=dout.dtype, device=dout.device)
+            _box_copy(dout, g, n, h, w, c, 0, 0, c0, d2, d3, 0)
+            grads.append(g)
+        return grads[0], grads[1], None, None
+
+
+class BNAct(torch.autograd.Function):
+    """act(BatchNorm2d(x)) on a tensor that does not come straight out of a conv (DIP: BN after Concat,
+    models/DIP/skip.py:51)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, c, cfg):
+        _need_gpu(x)
+        lib = _lib.lib()
+        x = x.contiguous()
+        cp = x.shape[-1]
+        p = x.numel() // cp
+        dev = x.device
+        train = bool(cfg["train"])
+        scale = torch.empty(cp, dtype=torch.float32, device=dev)
+        shift = torch.empty(cp, dtype=torch.float32, device=dev)
+        mean = torch.empty(cp, dtype=torch.float32, device=dev)
+        rstd = torch.empty(cp, dtype=torch.float32, device=dev)
+        if train:
+            blocks, rpb = _reduce_blocks(p)
+            part = torch.empty(blocks * 2 * cp, dtype=torch.float32, device=dev)
+            check(lib.dsr_pw_channel_stats(_dt(x), _ptr(x), p, cp, blocks, rpb, _ptr(part), _stream()))
+            check(lib.dsr_pw_bn_finalize(_ptr(part), blocks, cp, c, cp, float(p), _ptr(gamma), _ptr(beta),
+                                         _ptr(running_mean), _ptr(running_var), _ptr(nbt), BN_MOMENTUM, BN_EPS, 1,
+                                         _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
+        else:
+            check(lib.dsr_pw_bn_eval_affine(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), BN_EPS, c,
+                                            cp, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
+        act = cfg.get("act", ACT_NONE)
+        out = torch.empty_like(x)
+        check(lib.dsr_pw_bn_act_fwd(_dt(x), _ptr(x), _ptr(scale), _ptr(shift), None, _ptr(out), p, cp, act,
+                                    float(cfg.get("slope", 0.0)), None, _stream()))
+        ctx.cfg, ctx.act, ctx.train, ctx.p, ctx.c = cfg, act, train, p, c
+        ctx.save_for_backward(x, scale, shift, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, scale, shift, mean, rstd = ctx.saved_tensors
+        lib = _lib.lib()
+        dout = dout.contiguous()
+        cp = x.shape[-1]
+        dev = x.device
+        p, c = ctx.p, ctx.c
+        slope = float(ctx.cfg.get("slope", 0.0))
+        c1 = torch.empty(cp, dtype=torch.float32, device=dev)
+        c2 = torch.empty(cp, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        blocks, rpb = _reduce_blocks(p)
+        part = torch.empty(blocks * 3 * cp, dtype=torch.float32, device=dev)
+        check(lib.dsr_pw_bn_act_bwd_reduce(_dt(x), _ptr(dout), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
+                                           p, cp, blocks, rpb, ctx.act, slope, None, _ptr(part), _stream()))
+        check(lib.dsr_pw_bn_bwd_finalize(_ptr(part), blocks, c, cp, float(p), _ptr(dgamma), _ptr(dbeta), None, _ptr(c1),
+                                         _ptr(c2), _stream()))
+        dx = torch.empty_like(x)
+        check(lib.dsr_pw_bn_act_bwd_apply(_dt(x), _ptr(dout), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
+                                          _ptr(c1), _ptr(c2), _ptr(dx), p, cp, ctx.act, slope, None, int(ctx.train),
+                                          _stream()))
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class Downsample(torch.autograd.Function):
+    """Fixed-kernel strided depthwise correlation with ReplicationPad2d on fp32 NCHW (utils/downsampler.py:65-71)."""
+
+    @staticmethod
+    def forward(ctx, x, kern, factor, pad):
+        _need_gpu(x)
+        x = x.contiguous().float()
+        n, c, h, w = x.shape
+        k = kern.shape[0]
+        oh, ow = (h + 2 * pad - k) // factor + 1, (w + 2 * pad - k) // factor + 1
+        y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device)
+        check(_lib.lib().dsr_downsample_fwd(_ptr(x), _ptr(kern), _ptr(y), n * c, h, w, k, factor, pad, _stream()))
+        ctx.args = (n, c, h, w, k, factor, pad)
+        ctx.save_for_backward(kern)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (kern,) = ctx.saved_tensors
+        n, c, h, w, k, factor, pad = ctx.args
+        dy = dy.contiguous().float()
+        dx = torch.empty((n, c, h, w), dtype=torch.float32, device=dy.device)
+        check(_lib.lib().dsr_downsample_bwd(_ptr(dy), _ptr(kern), _ptr(dx), n * c, h, w, k, factor, pad, _stream()))
+        return dx, None, None, None

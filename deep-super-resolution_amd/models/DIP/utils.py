@@ -1,0 +1,167 @@
+"""Building blocks of the Deep-Image-Prior skip network with the reference's surface
+(/root/reference/models/DIP/utils.py): Concat (:10-41), act (:62-76), bn (:79-80), conv (:83-105).
+
+Module objects are structure + parameter holders (state_dict keys match the reference, including the
+1-indexed child names that its ``nn.Module.add`` monkey-patch produces); the arithmetic is done by
+``run_fused`` below, which walks a Sequential and dispatches fused HIP kernels:
+    [ReflectionPad2d] + Conv2d + BatchNorm2d + LeakyReLU  -> one ConvBNAct (padding folded into the tile loader)
+    Concat(skip, deeper)                                  -> both branches + channel box-copy with centre crop
+    BatchNorm2d on its own                                -> channel-stats + BN-apply kernels
+    Upsample(scale 2, bilinear)                           -> bilinear2x kernel
+    Conv2d + Sigmoid at the very end                      -> conv with sigmoid epilogue, fp32 NCHW output
+The reference's global monkey-patch of ``torch.nn.Module.add`` is not reproduced; ``add`` below is local.
+"""
+import torch
+import torch.nn as nn
+
+from ... import functional as F
+
+
+def add(seq, module):
+    """models/DIP/utils.py:5-8: children are named "1", "2", ..."""
+    seq.add_module(str(len(seq) + 1), module)
+
+
+class Concat(nn.Module):
+    def __init__(self, dim, *args):
+        super(Concat, self).__init__()
+        self.dim = dim
+        for idx, module in enumerate(args):
+            self.add_module(str(idx), module)
+
+    def __len__(self):
+        return len(self._modules)
+
+    def forward(self, input):
+        raise RuntimeError("Concat is executed by run_fused (models/DIP/utils.py of this package)")
+
+
+class GenNoise(nn.Module):
+    """Unused by skip() (the call site is commented out in the reference, skip.py:58); kept for the surface."""
+
+    def __init__(self, dim2):
+        super(GenNoise, self).__init__()
+        self.dim2 = dim2
+
+
+def act(act_fun='LeakyReLU'):
+    if isinstance(act_fun, str):
+        if act_fun == 'LeakyReLU':
+            return nn.LeakyReLU(0.2, inplace=True)
+        elif act_fun == 'ELU':
+            return nn.ELU()
+        elif act_fun == 'none':
+            return nn.Sequential()
+        else:
+            assert False
+    else:
+        return act_fun()
+
+
+def bn(num_features):
+    return nn.BatchNorm2d(num_features)
+
+
+def conv(in_f, out_f, kernel_size, stride=1, bias=True, pad='zero', downsample_mode='stride'):
+    downsampler = None
+    if stride != 1 and downsample_mode != 'stride':
+        if downsample_mode == 'avg':
+            downsampler = nn.AvgPool2d(stride, stride)
+        elif downsample_mode == 'max':
+            downsampler = nn.MaxPool2d(stride, stride)
+        else:
+            assert False
+        stride = 1
+    to_pad = int((kernel_size - 1) / 2)
+    padder = None
+    if pad == 'reflection':
+        padder = nn.ReflectionPad2d(to_pad)
+        to_pad = 0
+    convolver = nn.Conv2d(in_f, out_f, kernel_size, stride, padding=to_pad, bias=bias)
+    return nn.Sequential(*[m for m in (padder, convolver, downsampler) if m is not None])
+
+
+# ----------------------------------------------------------------------------- fused executor
+def _conv_parts(seq):
+    """A conv() Sequential -> (Conv2d, pad, pad_mode) or None if `seq` is not one."""
+    if not isinstance(seq, nn.Sequential) or len(seq) == 0:
+        return None
+    mods = list(seq.children())
+    pad_mode, pad = F.PAD_ZERO, 0
+    if isinstance(mods[0], nn.ReflectionPad2d):
+        pad_mode, pad = F.PAD_REFLECT, int(mods[0].padding[0])
+        mods = mods[1:]
+    if len(mods) != 1 or not isinstance(mods[0], nn.Conv2d):
+        if mods and isinstance(mods[0], nn.Conv2d):
+            raise NotImplementedError("downsample_mode 'avg'/'max' (pool after conv) is not on the HIP path yet")
+        return None
+    c = mods[0]
+    if pad_mode == F.PAD_ZERO:
+        pad = int(c.padding[0])
+    elif pad == 0:
+        pad_mode = F.PAD_ZERO
+    return c, pad, pad_mode
+
+
+def _is_leaky(m):
+    return isinstance(m, nn.LeakyReLU)
+
+
+def run_fused(seq, x, c, train):
+    """Execute an nn.Sequential built by skip() on an NHWC 16-bit tensor x with c real channels."""
+    mods = list(seq.children())
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        cp = _conv_parts(m)
+        if cp is not None:
+            cv, pad, pmode = cp
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            nxt2 = mods[i + 2] if i + 2 < len(mods) else None
+            if isinstance(nxt, nn.BatchNorm2d):
+                a, slope, step = F.ACT_NONE, 0.0, 2
+                if _is_leaky(nxt2):
+                    a, slope, step = F.ACT_LEAKY, float(nxt2.negative_slope), 3
+                elif isinstance(nxt2, nn.Sequential) and len(nxt2) == 0:       # act('none')
+                    step = 3
+                elif isinstance(nxt2, nn.ELU):
+                    raise NotImplementedError("act_fun='ELU' is not on the HIP path yet")
+                cfg = dict(stride=int(cv.stride[0]), pad=pad, pad_mode=pmode, act=a, slope=slope, train=train)
+                x = F.ConvBNAct.apply(x, cv.weight, cv.bias, nxt.weight, nxt.bias, nxt.running_mean, nxt.running_var,
+                                      nxt.num_batches_tracked, None, None, cfg)
+                c = cv.out_channels
+                i += step
+                continue
+            if isinstance(nxt, nn.Sigmoid) and i + 2 == len(mods):
+                return F.ConvOutNCHW.apply(x, cv.weight, cv.bias, dict(stride=int(cv.stride[0]), pad=pad, pad_mode=pmode,
+                                                                       act=F.ACT_SIGMOID)), cv.out_channels
+            x = F.ConvAct.apply(x, cv.weight, cv.bias, None, dict(stride=int(cv.stride[0]), pad=pad, pad_mode=pmode,
+                                                                   act=F.ACT_NONE))
+            c = cv.out_channels
+            i += 1
+            continue
+        if isinstance(m, Concat):
+            outs = [run_fused(b, x, c, train) for b in m.children()]
+            assert len(outs) == 2, "skip() builds two-branch Concats"
+            (ta, ca), (tb, cb) = outs
+            x, c = F.ConcatCrop.apply(ta, tb, ca, cb), ca + cb
+        elif isinstance(m, nn.BatchNorm2d):
+            a, slope, step = F.ACT_NONE, 0.0, 1
+            if i + 1 < len(mods) and _is_leaky(mods[i + 1]):
+                a, slope, step = F.ACT_LEAKY, float(mods[i + 1].negative_slope), 2
+            x = F.BNAct.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked, c,
+                              dict(act=a, slope=slope, train=train))
+            i += step
+            continue
+        elif isinstance(m, nn.Upsample):
+            if m.mode != 'bilinear' or float(m.scale_factor) != 2.0:
+                raise NotImplementedError("only Upsample(scale_factor=2, mode='bilinear') is on the HIP path yet")
+            x = F.Bilinear2x.apply(x)
+        elif isinstance(m, nn.Sequential):
+            x, c = run_fused(m, x, c, train)
+        elif isinstance(m, nn.Sigmoid):
+            raise NotImplementedError("Sigmoid must follow the last conv (need_sigmoid=True layout of skip())")
+        else:
+            raise NotImplementedError(f"module {type(m).__name__} has no HIP kernel on this path")
+        i += 1
+    return x, c

@@ -1,0 +1,70 @@
+"""SRGAN discriminator with the reference's nn.Module surface, computed by the HIP kernels.
+
+Mirror of /root/reference/models/GAN/discriminator.py (DiscriminatorConvBlock :4-19, Discriminator
+:21-74): same constructor, child names (conv, convblocks.{i}.{conv1,bn1}, dense1, dense2), parameter
+shapes -- dense1.weight is [1024, 512*H/16*W/16] in the reference's C,H,W flatten order -- and default
+initialisation order.  ``fc_input_shape`` (:48-56) is computed arithmetically instead of by a dry
+forward through torch (same number; a dry run would need the GPU at construction time).
+"""
+import torch
+import torch.nn as nn
+
+from ... import functional as F
+
+
+class DiscriminatorConvBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, stride):
+        super(DiscriminatorConvBlock, self).__init__()
+        self.conv1 = nn.Conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=3, stride=stride, padding=1)
+        self.bn1 = nn.BatchNorm2d(num_features=out_channels)
+        self.leakyrelu = nn.LeakyReLU(negative_slope=0.2)
+        self.stride = stride
+        self.compute_dtype = torch.bfloat16
+
+    def _block(self, x):
+        cfg = dict(stride=self.stride, pad=1, act=F.ACT_LEAKY, slope=0.2, train=self.training)
+        return F.ConvBNAct.apply(x, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias,
+                                 self.bn1.running_mean, self.bn1.running_var, self.bn1.num_batches_tracked,
+                                 None, None, cfg)                                           # discriminator.py:15-17
+
+    def forward(self, x):
+        if x.dtype in (torch.bfloat16, torch.float16):
+            return self._block(x)
+        cout = self.conv1.out_channels
+        return F.ToNCHW.apply(self._block(F.ToNHWC.apply(x, self.compute_dtype)), cout)
+
+
+class Discriminator(nn.Module):
+    def __init__(self, HR_image_shape):
+        super(Discriminator, self).__init__()
+        self.conv = nn.Conv2d(in_channels=3, out_channels=64, kernel_size=3, stride=1, padding=1)
+        self.leakyrelu1 = nn.LeakyReLU(negative_slope=0.2)
+        self.convblocks = nn.Sequential(*[DiscriminatorConvBlock(in_channels=64, out_channels=64, stride=2),
+                                          DiscriminatorConvBlock(in_channels=64, out_channels=128, stride=1),
+                                          DiscriminatorConvBlock(in_channels=128, out_channels=128, stride=2),
+                                          DiscriminatorConvBlock(in_channels=128, out_channels=256, stride=1),
+                                          DiscriminatorConvBlock(in_channels=256, out_channels=256, stride=2),
+                                          DiscriminatorConvBlock(in_channels=256, out_channels=512, stride=1),
+                                          DiscriminatorConvBlock(in_channels=512, out_channels=512, stride=2)])
+        dense1_shape = self.fc_input_shape(HR_image_shape)
+        self.dense1 = nn.Linear(in_features=dense1_shape, out_features=1024)
+        self.leakyrelu2 = nn.LeakyReLU(negative_slope=0.2)
+        self.dense2 = nn.Linear(1024, 1)
+        self.sigmoid = nn.Sigmoid()
+        self.compute_dtype = torch.bfloat16
+
+    def fc_input_shape(self, HR_image_shape):
+        h, w = int(HR_image_shape[0]), int(HR_image_shape[1])
+        for blk in self.convblocks:
+            s = blk.stride
+            h, w = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+        return 512 * h * w
+
+    def forward(self, x):
+        xi = F.ToNHWC.apply(x, self.compute_dtype)
+        z = F.ConvAct.apply(xi, self.conv.weight, self.conv.bias, None,
+                            dict(stride=1, pad=1, act=F.ACT_LEAKY, slope=0.2))            # :60-61
+        for blk in self.convblocks:                                                           # :63
+            z = blk._block(z)
+        return F.DenseHead.apply(z, self.dense1.weight, self.dense1.bias, self.dense2.weight, self.dense2.bias,
+                                 512)                                                          # :65-72

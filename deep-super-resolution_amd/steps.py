@@ -16,3 +16,54 @@ def gen_l1_step(gen, opt, lr_patches, hr_patches):
     loss.backward()
     opt.step()
     return loss.detach(), fake.detach()
+
+
+def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches):
+    """train_GAN.py:38-71.  Returns (loss_D, loss_G, fake) as device tensors (no host sync here)."""
+    # --- discriminator
+    real_d = disc(hr_patches)                                    # :44
+    fake = gen(lr_patches).detach()                              # :46
+    fake_d = disc(fake)                                          # :47
+    loss_d = F.bce_const(real_d, 1.0) + F.bce_const(fake_d, 0.0)  # :48, utils/GAN.py:101-105
+    opt_d.zero_grad()                                            # :51 (gan_D.zero_grad())
+    loss_d.backward()                                            # :52
+    opt_d.step()                                                 # :53
+    # --- generator
+    fake = gen(lr_patches)                                       # :56
+    with torch.no_grad():
+        # :58 detaches the generator output, so this D pass never sends a gradient anywhere that survives
+        # (D's .grad from it is wiped by the next zero_grad, :51); it still updates D's BN running statistics.
+        fake_d = disc(fake.detach())
+    loss_g = perceptual(fake, hr_patches, fake_d, None)          # :59
+    opt_g.zero_grad()                                            # :62
+    loss_g.backward()                                            # :63
+    opt_g.step()                                                 # :64
+    return loss_d.detach(), loss_g.detach(), fake.detach()
+
+
+class DipRunner:
+    """DIP.py:22-123 state: fixed noise input, jitter buffer, Lanczos downsampler, Adam over the net."""
+
+    def __init__(self, net, downsampler, net_input, lr_image, learning_rate, reg_noise_std):
+        from .optim import FusedAdam
+        self.net, self.down = net, downsampler
+        self.net_input_saved = net_input.detach().clone()        # DIP.py:33
+        self.noise = net_input.detach().clone()                  # DIP.py:34
+        self.net_input = net_input
+        self.lr_image = lr_image
+        self.sigma = reg_noise_std
+        self.opt = FusedAdam(list(net.parameters()), lr=learning_rate)   # get_params('net') + utils/DIP.py:34
+
+    def step(self, noise=None):
+        """optimizer.zero_grad(); closure(); optimizer.step()  (utils/DIP.py:35-38, DIP.py:47-68)."""
+        self.opt.zero_grad()
+        if self.sigma > 0:
+            if noise is None:
+                noise = self.noise.normal_()                     # DIP.py:52 (torch RNG on whatever device holds it)
+            self.net_input = self.net_input_saved + noise * self.sigma
+        out_hr = self.net(self.net_input)                        # :60
+        out_lr = self.down(out_hr)                               # :62
+        loss = F.mse_loss(out_lr, self.lr_image)                 # :65
+        loss.backward()                                          # :68
+        self.opt.step()
+        return loss.detach(), out_hr.detach()

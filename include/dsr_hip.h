@@ -126,6 +126,53 @@ int dsr_pw_adam(float* p, const float* g, float* m, float* v, size_t n, float lr
                 const int* step, dsr_stream_t s);
 int dsr_pw_incr(int* step, dsr_stream_t s);
 
+/* ------------------------------------------------------------------ discriminator dense head (linear.hip)
+ * models/GAN/discriminator.py:37-45,65-72: flatten(C,H,W) -> Linear(K,O) -> LeakyReLU(0.2) -> Linear(O,1) -> Sigmoid */
+/* 16-bit shadow copy of an fp32 tensor (n % 8 == 0) */
+int dsr_cast16(int dtype, const float* src, void* dst, size_t n, dsr_stream_t s);
+/* mode 0: flat[b][c*HW+p] = act[b][p][c];  1: flatT[c*HW+p][b] (Bp columns, zero padded);  2: act <- flat */
+int dsr_flatten(int dtype, const void* src, void* dst, int B, int HW, int C, int Cp, int Bp, int mode, dsr_stream_t s);
+size_t dsr_linear_fwd_workspace(int B, size_t K, int O);
+/* out[b][o] (fp32) = act(sum_k x[b][k] w16[o][k] + bias[o]) */
+int dsr_linear_fwd(int dtype, const void* x, const void* w16, const float* bias, int act, float slope, float* out,
+                   int B, size_t K, int O, void* workspace, size_t ws_bytes, dsr_stream_t s);
+/* dx[b][k] (16-bit) = sum_o dy16[b][o] w16[o][k] */
+int dsr_linear_dgrad(int dtype, const void* dy16, const void* w16, void* dx, int B, int O, size_t K, dsr_stream_t s);
+/* dw[o][k] (fp32, overwritten) = sum_b dyT16[o][b] xT16[k][b];  Bp in {32, 64} */
+int dsr_linear_wgrad(int dtype, const void* dyT16, const void* xT16, float* dw, int Bp, int O, size_t K,
+                     dsr_stream_t s);
+/* out[b] = sigmoid(h[b][:] . w2 + b2) */
+int dsr_dense2_fwd(const float* h, const float* w2, const float* b2, int B, int K1, float* out, dsr_stream_t s);
+/* backward of the fp32 tail; also emits the 16-bit dy / dy^T operands of the two dense1 GEMMs */
+int dsr_dense2_bwd(int dtype, const float* dout, const float* out, const float* h, const float* w2, int B, int K1,
+                   int Bp, float slope, float* dw2, float* db2, float* db1, void* dy16, void* dyT16, dsr_stream_t s);
+
+/* ------------------------------------------------------------------ resampling / data movement (resample.hip) */
+/* nn.MaxPool2d(2,2) of the VGG19 trunk (utils/GAN.py:24,29,38,47); backward routes to the first maximum */
+int dsr_maxpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t s);
+int dsr_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int Cp, dsr_stream_t s);
+/* nn.Upsample(scale_factor=2, mode='bilinear') (models/DIP/skip.py:77); H, W are the INPUT size */
+int dsr_bilinear2x_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t s);
+int dsr_bilinear2x_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, dsr_stream_t s);
+/* VGG19_Weights.IMAGENET1K_V1.transforms() (utils/GAN.py:82-83): separable antialiased resize + crop + normalise.
+ * src fp32 NCHW [N][C<=3][H][W] -> dst NHWC 16-bit [N][OH][OW][8]; tables are host-built (utils/GAN.py mirror):
+ * per output index start/count/weights[KT]; the backward takes the transposed tables. */
+int dsr_resize_norm_fwd(int dtype, const float* src, void* dst, int N, int C, int H, int W, int OH, int OW,
+                        const int* ys, const int* yc, const float* yw, const int* xs, const int* xc, const float* xw,
+                        int KT, const float* mean3, const float* std3, dsr_stream_t s);
+int dsr_resize_norm_bwd(int dtype, const void* dout, float* dsrc, int N, int C, int H, int W, int OH, int OW,
+                        const int* ty_s, const int* ty_c, const float* ty_w, const int* tx_s, const int* tx_c,
+                        const float* tx_w, int KT, const float* std3, dsr_stream_t s);
+/* Concat with centre crop (models/DIP/utils.py:18-38) and its adjoint: 16-bit NHWC box copy
+ * dst[n][dy0+y][dx0+x][cd0+c] = src[n][sy0+y][sx0+x][cs0+c], y<BH, x<BW, c<C */
+int dsr_box_copy(const void* src, void* dst, int N, int BH, int BW, int C, int SH, int SW, int SCp, int sy0, int sx0,
+                 int cs0, int DH, int DW, int DCp, int dy0, int dx0, int cd0, dsr_stream_t s);
+/* Downsampler (utils/downsampler.py:44-71): depthwise k x k kernel, stride f, ReplicationPad2d(p); fp32 NCHW, NC = N*C */
+int dsr_downsample_fwd(const float* x, const float* kern, float* y, int NC, int H, int W, int k, int f, int p,
+                       dsr_stream_t s);
+int dsr_downsample_bwd(const float* dy, const float* kern, float* dx, int NC, int H, int W, int k, int f, int p,
+                       dsr_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

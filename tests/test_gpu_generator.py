@@ -67,13 +67,26 @@ def test_generator_train_fwd_bwd(dev, factor, nres, shape):
     assert err <= 0.06 and psnr >= 34.0, (err, psnr)
     gx = xg.grad.cpu()
     assert cos(gx, xr.grad) >= 0.98, cos(gx, xr.grad)
+    # conditioning probe: the same oracle with parameters and input rounded to bf16.  How far ITS gradients
+    # move is the noise floor any bf16 implementation has on this (deliberately small-batch) network; the
+    # one-element PReLU gradients are sums with heavy cancellation and are judged against that floor.
+    nsd = {k: (v.to(torch.bfloat16).float() if v.dtype == torch.float32 else v.clone()) for k, v in sd.items()}
+    recipes.leaves(nsd)
+    yn = gan.generator_forward(nsd, x.to(torch.bfloat16).float(), True)
+    (yn * probe).sum().backward()
     bad = []
     for k, p in g.named_parameters():
         ref = osd[k].grad
         if ref.abs().sum() < 1e-3 * max(1.0, ref.numel() ** 0.5):     # pre-BN biases: analytically zero
             continue
-        c = cos(p.grad.cpu(), ref)
-        ratio = float(p.grad.norm().cpu() / ref.norm())
+        got = p.grad.cpu()
+        if ref.numel() == 1:
+            floor = float((nsd[k].grad - ref).abs())
+            if float((got - ref).abs()) > 4.0 * floor + 0.05 * float(ref.abs()):
+                bad.append((k, float(got), float(ref), floor))
+            continue
+        c = cos(got, ref)
+        ratio = float(got.norm() / ref.norm())
         if c < 0.98 or not (0.9 < ratio < 1.1):
             bad.append((k, c, ratio))
     assert not bad, bad
@@ -89,8 +102,19 @@ def test_generator_eval_matches_golden(dev, golden):
     """Eval mode (running statistics): compare with the reference's own float64 output."""
     z = golden("generator_g4_r2")
     g, _ = build(dev, 4, 2)
-    g.eval()
     x = filler.tensor("in:g4_r2", (2, 3, 8, 8), 0.5, 0.5)
+    # same sequence as tests/golden/make_golden.py: two train-mode forwards (running stats updated twice), then eval
+    g.train()
+    with torch.no_grad():
+        g(x.to(dev))
+        g(x.to(dev))
+    for k, v in g.state_dict().items():
+        if "running_" in k:
+            ref = z["buf2/" + k]
+            assert np.abs(v.cpu().numpy() - ref).max() <= 3e-2 * max(1.0, np.abs(ref).max()), k
+        if "num_batches" in k:
+            assert int(v) == 2
+    g.eval()
     with torch.no_grad():
         y = g(x.to(dev))
     torch.cuda.synchronize()

@@ -1,0 +1,318 @@
+"""GPU: discriminator, VGG perceptual loss, DIP skip net, downsampler and the GAN / DIP step recipes on the HIP
+path against the CPU oracle (fp32) on identical parameters and inputs.  bf16 tolerances are stated inline."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from oracle import dip, downsampler, filler, gan, losses, recipes, vgg
+
+pytestmark = pytest.mark.gpu
+PKG = "deep-super-resolution_amd"
+
+
+def P(sub):
+    return importlib.import_module(PKG + "." + sub)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    P("_lib").lib()
+    return torch.device("cuda:0")
+
+
+def bfr(t):
+    return t.to(torch.bfloat16).float()
+
+
+def rel_err(got, ref):
+    got, ref = got.double(), ref.double()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-20))
+
+
+def cos(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-30))
+
+
+def to_nhwc(x):
+    n, c, h, w = x.shape
+    cp = (c + 7) // 8 * 8
+    out = torch.zeros(n, h, w, cp, dtype=torch.bfloat16)
+    out[..., :c] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    return out
+
+
+def from_nhwc(y, c):
+    return y[..., :c].float().permute(0, 3, 1, 2).contiguous()
+
+
+# ----------------------------------------------------------------------------- single ops
+def test_dense_head(dev):
+    F = P("functional")
+    n, c, h, w = 5, 512, 2, 3
+    k = c * h * w
+    x = bfr(filler.tensor("dh:x", (n, c, h, w)))
+    w1 = bfr(filler.tensor("dh:w1", (1024, k), float(np.sqrt(3.0 / k))))
+    b1 = filler.tensor("dh:b1", (1024,), 0.1)
+    w2 = filler.tensor("dh:w2", (1, 1024), float(np.sqrt(3.0 / 1024)))
+    b2 = filler.tensor("dh:b2", (1,), 0.1)
+    xr, w1r, b1r, w2r, b2r = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    hr = TF.leaky_relu(TF.linear(xr.reshape(n, -1), w1r, b1r), 0.2)
+    outr = torch.sigmoid(TF.linear(hr, w2r, b2r))
+    probe = filler.tensor("dh:p", (n, 1))
+    (outr * probe).sum().backward()
+    xg = to_nhwc(x).to(dev).requires_grad_(True)
+    gs = [t.to(dev).requires_grad_(True) for t in (w1, b1, w2, b2)]
+    out = F.DenseHead.apply(xg, *gs, c)
+    out.backward(probe.to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(out.detach().cpu(), outr.detach()) < 5e-3
+    assert rel_err(from_nhwc(xg.grad.cpu(), c), xr.grad) < 2e-2
+    for got, ref, name in zip(gs, (w1r, b1r, w2r, b2r), ("w1", "b1", "w2", "b2")):
+        assert rel_err(got.grad.cpu(), ref.grad) < 2e-2, name
+
+
+def test_maxpool_bilinear_concat(dev):
+    F = P("functional")
+    x = bfr(filler.tensor("mp:x", (2, 16, 6, 10)))
+    xr = x.clone().requires_grad_(True)
+    yr = TF.max_pool2d(xr, 2, 2)
+    probe = bfr(filler.tensor("mp:p", tuple(yr.shape)))
+    (yr * probe).sum().backward()
+    xg = to_nhwc(x).to(dev).requires_grad_(True)
+    yg = F.MaxPool2.apply(xg)
+    yg.backward(to_nhwc(probe).to(dev))
+    assert torch.equal(from_nhwc(yg.detach().cpu(), 16), yr.detach())
+    assert torch.equal(from_nhwc(xg.grad.cpu(), 16), xr.grad)
+    # bilinear x2
+    x = bfr(filler.tensor("bl:x", (2, 8, 5, 7)))
+    xr = x.clone().requires_grad_(True)
+    yr = TF.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=False)
+    probe = bfr(filler.tensor("bl:p", tuple(yr.shape)))
+    (yr * probe).sum().backward()
+    xg = to_nhwc(x).to(dev).requires_grad_(True)
+    yg = F.Bilinear2x.apply(xg)
+    yg.backward(to_nhwc(probe).to(dev))
+    assert rel_err(from_nhwc(yg.detach().cpu(), 8), yr.detach()) < 5e-3
+    assert rel_err(from_nhwc(xg.grad.cpu(), 8), xr.grad) < 5e-3
+    # concat with centre crop, channel counts that are not multiples of 8
+    a = bfr(filler.tensor("cc:a", (1, 4, 10, 12)))
+    b = bfr(filler.tensor("cc:b", (1, 13, 8, 8)))
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = dip.concat_center_crop([ar, br])
+    probe = bfr(filler.tensor("cc:p", tuple(yr.shape)))
+    (yr * probe).sum().backward()
+    ag, bg = to_nhwc(a).to(dev).requires_grad_(True), to_nhwc(b).to(dev).requires_grad_(True)
+    yg = F.ConcatCrop.apply(ag, bg, 4, 13)
+    assert tuple(yg.shape) == (1, 8, 8, 24)
+    yg.backward(to_nhwc(probe).to(dev))
+    assert torch.equal(from_nhwc(yg.detach().cpu(), 17), yr.detach())
+    assert float(yg.detach()[..., 17:].float().abs().max()) == 0.0
+    assert torch.equal(from_nhwc(ag.grad.cpu(), 4), ar.grad) and torch.equal(from_nhwc(bg.grad.cpu(), 13), br.grad)
+
+
+def test_bn_act_standalone(dev):
+    F = P("functional")
+    c = 132
+    x = bfr(filler.tensor("bna:x", (2, c, 6, 6)))
+    gamma, beta = filler.tensor("bna:g", (c,), 0.2, 1.0), filler.tensor("bna:b", (c,), 0.1)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    yr = TF.batch_norm(xr, rm, rv, gr, br, training=True, momentum=0.1, eps=1e-5)
+    probe = bfr(filler.tensor("bna:p", tuple(yr.shape)))
+    (yr * probe).sum().backward()
+    xg = to_nhwc(x).to(dev).requires_grad_(True)
+    gg, bg = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+    rmg, rvg, nbt = torch.zeros(c, device=dev), torch.ones(c, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
+    yg = F.BNAct.apply(xg, gg, bg, rmg, rvg, nbt, c, dict(act=F.ACT_NONE, train=True))
+    yg.backward(to_nhwc(probe).to(dev))
+    assert rel_err(from_nhwc(yg.detach().cpu(), c), yr.detach()) < 1e-2
+    assert rel_err(from_nhwc(xg.grad.cpu(), c), xr.grad) < 3e-2
+    assert rel_err(gg.grad.cpu(), gr.grad) < 2e-2 and rel_err(bg.grad.cpu(), br.grad) < 2e-2
+    assert rel_err(rmg.cpu(), rm) < 1e-3 and rel_err(rvg.cpu(), rv) < 1e-3
+
+
+@pytest.mark.parametrize("shape,resize,crop", [((2, 3, 40, 40), 32, 28), ((1, 3, 16, 24), 32, 28), ((1, 3, 64, 64), 256, 224)])
+def test_resize_norm(dev, shape, resize, crop):
+    F, G = P("functional"), P("utils.GAN")
+    x = filler.tensor("rn:x" + str(shape), shape)
+    xr = x.clone().requires_grad_(True)
+    yr = vgg.preprocess(xr, resize, crop)
+    probe = bfr(filler.tensor("rn:p" + str(shape), tuple(yr.shape)))
+    (yr * probe).sum().backward()
+    tab = G.ResampleTables(shape[2], shape[3], dev, resize, crop)
+    xg = x.to(dev).requires_grad_(True)
+    yg = F.ResizeNorm.apply(xg, tab, torch.bfloat16)
+    assert tuple(yg.shape) == (shape[0], crop, crop, 8)
+    yg.backward(to_nhwc(probe).to(dev))
+    assert rel_err(from_nhwc(yg.detach().cpu(), 3), yr.detach()) < 6e-3
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-4
+
+
+def test_downsampler_module(dev, golden):
+    D = P("utils.downsampler")
+    z = golden("downsampler")
+    for f in (2, 4, 8):
+        d = D.Downsampler(3, f, "lanczos2", phase=0.5, preserve_size=True).to(dev)
+        np.testing.assert_allclose(d.kernel, z[f"kernel_f{f}"], rtol=1e-12, atol=1e-15)
+        assert tuple(d.downsampler_.weight.shape) == (3, 3, 4 * f, 4 * f)
+        x = filler.tensor(f"in:down{f}", (1, 3, 32, 32), 0.5, 0.5).to(dev).requires_grad_(True)
+        y = d(x)
+        probe = filler.tensor(f"probe:down{f}", tuple(y.shape))
+        (y * probe.to(dev)).sum().backward()
+        np.testing.assert_allclose(y.detach().cpu().numpy(), z[f"y_f{f}"], rtol=2e-5, atol=2e-6)      # fp32 kernel
+        np.testing.assert_allclose(x.grad.cpu().numpy(), z[f"gx_f{f}"], rtol=2e-5, atol=2e-6)
+    x = filler.tensor("in:downl3", (2, 3, 16, 20), 0.5, 0.5).to(dev)
+    for tag, args in (("l3", dict(factor=2, kernel_type="lanczos3", phase=0, preserve_size=True)),
+                      ("g12", dict(factor=2, kernel_type="gauss12", phase=0, preserve_size=True)),
+                      ("box", dict(factor=4, kernel_type="box", phase=0.5, kernel_width=4, preserve_size=False))):
+        d = D.Downsampler(3, **args).to(dev)
+        np.testing.assert_allclose(d(x).cpu().numpy(), z["y_" + tag], rtol=2e-5, atol=2e-6)
+    with pytest.raises(AssertionError):
+        D.Downsampler(3, 2, "nope")
+
+
+# ----------------------------------------------------------------------------- modules
+def grads_ok(module, osd, min_cos=0.97, ratio=0.12):
+    bad = []
+    for k, p in module.named_parameters():
+        if p.grad is None:
+            continue
+        ref = osd[k].grad
+        if ref is None or ref.abs().sum() < 1e-3 * max(1.0, ref.numel() ** 0.5) or ref.numel() == 1:
+            continue
+        c = cos(p.grad.cpu(), ref)
+        r = float(p.grad.norm().cpu() / ref.norm())
+        if c < min_cos or abs(r - 1) > ratio:
+            bad.append((k, round(c, 4), round(r, 4)))
+    return bad
+
+
+@pytest.mark.parametrize("hw,n", [((32, 32), 4), ((48, 32), 3), ((64, 64), 4)])
+def test_discriminator(dev, hw, n):
+    Dm = P("models.GAN.discriminator")
+    sd = filler.fill_state_dict(gan.template(gan.discriminator_shapes(hw)))
+    d = Dm.Discriminator(hw)
+    assert list(d.state_dict().keys()) == list(sd.keys())
+    assert all(tuple(d.state_dict()[k].shape) == tuple(sd[k].shape) for k in sd)
+    d.load_state_dict(sd)
+    d.to(dev).train()
+    x = filler.tensor("in:disc" + str(hw), (n, 3, hw[0], hw[1]))
+    xg = x.to(dev).requires_grad_(True)
+    y = d(xg)
+    assert tuple(y.shape) == (n, 1) and y.dtype == torch.float32
+    probe = filler.tensor("probe:disc" + str(hw), (n, 1))
+    (y * probe.to(dev)).sum().backward()
+    osd = {k: v.clone() for k, v in sd.items()}
+    recipes.leaves(osd)
+    xr = x.clone().requires_grad_(True)
+    yr = gan.discriminator_forward(osd, xr, True)
+    (yr * probe).sum().backward()
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() < 0.03          # probabilities in (0,1)
+    assert cos(xg.grad.cpu(), xr.grad) > 0.97
+    assert not grads_ok(d, osd), grads_ok(d, osd)
+    for k, v in d.state_dict().items():
+        if "running_" in k:
+            assert rel_err(v.cpu(), osd[k]) < 2e-2, k
+
+
+def test_vgg_loss(dev):
+    G = P("utils.GAN")
+    m = G.Vgg19Loss(resize_to=48, crop=40).to(dev)
+    keys = list(m.state_dict().keys())
+    assert keys[0] == "net.0.0.weight" and keys[-1] == "net.0.34.bias" and len(keys) == 32
+    osd = {k[len("net.0."):]: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    a = filler.tensor("vgg:a", (2, 3, 64, 64))
+    b = filler.tensor("vgg:b", (2, 3, 64, 64))
+    ar = a.clone().requires_grad_(True)
+    lref = vgg.vgg_loss(osd, ar, b, 48, 40)
+    lref.backward()
+    ag = a.to(dev).requires_grad_(True)
+    l = m(ag, b.to(dev))
+    l.backward()
+    assert abs(l.item() - lref.item()) < 3e-2 * abs(lref.item()), (l.item(), lref.item())
+    assert cos(ag.grad.cpu(), ar.grad) > 0.97, cos(ag.grad.cpu(), ar.grad)
+    assert abs(float(ag.grad.norm().cpu() / ar.grad.norm()) - 1) < 0.1
+
+
+DIP_CASES = [("small", (1, 8, 32, 32), dict(skip_n33d=16, skip_n33u=16, skip_n11=4, num_scales=3)),
+             ("full64", (1, 32, 64, 64), {}), ("crop72x104", (1, 32, 72, 104), {})]
+
+
+@pytest.mark.parametrize("tag,shape,kw", DIP_CASES)
+def test_dip_skip_net(dev, tag, shape, kw):
+    M = P("models.DIP")
+    cfg = dip.SkipConfig(input_depth=shape[1], **kw)
+    sd = filler.fill_state_dict(gan.template(dip.skip_shapes(cfg)))
+    net = M.get_net(shape[1], "skip", "reflection", upsample_mode="bilinear", **kw)
+    assert set(net.state_dict().keys()) == set(sd.keys())
+    net.load_state_dict(sd)
+    net.to(dev).train()
+    x = filler.tensor("in:dipg_" + tag, shape, 0.05, 0.05)
+    xg = x.to(dev).requires_grad_(True)
+    y = net(xg)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (shape[0], 3, shape[2], shape[3])
+    probe = filler.tensor("probe:dipg_" + tag, tuple(y.shape))
+    (y * probe.to(dev)).sum().backward()
+    osd = {k: v.clone() for k, v in sd.items()}
+    recipes.leaves(osd)
+    xr = x.clone().requires_grad_(True)
+    yr = dip.skip_forward(osd, xr, cfg, True)
+    (yr * probe).sum().backward()
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() < 0.04          # sigmoid output in (0,1)
+    bad = grads_ok(net, osd, 0.95, 0.2)
+    assert len(bad) <= 2, bad          # deepest 2x2 / 3x3 BatchNorm layers are noise-limited in bf16
+
+
+# ----------------------------------------------------------------------------- step recipes
+def test_gan_step_vs_oracle(dev):
+    """train_GAN.py:38-71 for 2 steps on small shapes; stand-in VGG (resize 32 / crop 28)."""
+    Gm, Dm, GANu, optim, steps = P("models.GAN.generator"), P("models.GAN.discriminator"), P("utils.GAN"), P("optim"), P("steps")
+    gsd = filler.fill_state_dict(gan.template(gan.generator_shapes(4, 2)))
+    dsd = filler.fill_state_dict(gan.template(gan.discriminator_shapes((64, 64))))
+    g, d = Gm.Generator(4, 2), Dm.Discriminator((64, 64))
+    g.load_state_dict(gsd), d.load_state_dict(dsd)
+    g.to(dev).train(), d.to(dev).train()
+    perc = GANu.PerceptualLoss(resize_to=32, crop=28).to(dev)
+    vsd = {k[len("vgg_loss.net.0."):]: v.detach().cpu().clone() for k, v in perc.state_dict().items()}
+    og, od = optim.FusedAdam(g.parameters(), lr=1e-4), optim.FusedAdam(d.parameters(), lr=1e-4)
+    st = recipes.GanState({k: v.clone() for k, v in gsd.items()}, {k: v.clone() for k, v in dsd.items()}, vsd, lr=1e-4,
+                          vgg_resize=32, vgg_crop=28)
+    lr = filler.tensor("in:gs_lr", (4, 3, 16, 16), 0.5, 0.5)
+    hr = filler.tensor("in:gs_hr", (4, 3, 64, 64))
+    for it in range(2):
+        ld, lg, fake = steps.gan_step(g, d, perc, og, od, lr.to(dev), hr.to(dev))
+        rld, rlg, rfake = recipes.gan_step(st, lr, hr)
+        assert abs(ld.item() - rld) < 0.05 * max(abs(rld), 0.1), (it, ld.item(), rld)
+        assert abs(lg.item() - rlg) < 0.05 * max(abs(rlg), 0.1), (it, lg.item(), rlg)
+        assert abs(losses.psnr(fake.cpu(), hr) - losses.psnr(rfake, hr)) <= 0.05
+    for k, v in d.state_dict().items():          # three D forwards per step update the running statistics 3x
+        if "num_batches" in k:
+            assert int(v) == 6 == int(st.d[k])
+
+
+def test_dip_step_vs_oracle(dev):
+    M, D, steps = P("models.DIP"), P("utils.downsampler"), P("steps")
+    kw = dict(skip_n33d=16, skip_n33u=16, skip_n11=4, num_scales=3)
+    cfg = dip.SkipConfig(input_depth=8, **kw)
+    sd = filler.fill_state_dict(gan.template(dip.skip_shapes(cfg)))
+    net = M.get_net(8, "skip", "reflection", upsample_mode="bilinear", **kw)
+    net.load_state_dict(sd)
+    net.to(dev).train()
+    down = D.Downsampler(3, 2, "lanczos2", phase=0.5, preserve_size=True).to(dev)
+    hr = filler.tensor("in:ds_hr", (1, 3, 32, 32), 0.5, 0.5)
+    lr_img = downsampler.downsampler_forward(hr, 2, "lanczos2", phase=0.5, preserve_size=True)
+    zin = filler.tensor("in:ds_z", (1, 8, 32, 32), 0.05, 0.05)
+    run = steps.DipRunner(net, down, zin.to(dev), lr_img.to(dev), 0.01, 0.05)
+    st = recipes.DipState({k: v.clone() for k, v in sd.items()}, cfg, zin.clone(), factor=2, lr=0.01, reg_noise_std=0.05)
+    for it in range(3):
+        noise = filler.tensor(f"in:ds_noise{it}", (1, 8, 32, 32), 1.7)
+        loss, out = run.step(noise.to(dev))
+        rloss, rout = recipes.dip_step(st, lr_img, noise)
+        assert abs(loss.item() - rloss) < 0.03 * abs(rloss), (it, loss.item(), rloss)
+        assert (out.cpu() - rout).abs().max().item() < 0.05
