@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- HR-pixel throughput of the x4 SRGAN train step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload gan_x4|gen_l1_x4]
+
+A "step" is one pass of the hot path over one synthetic batch already resident in HBM:
+  gan_x4    : BASELINE config 3 -- full GAN step (train_GAN.py:38-71 recipe: D step, G step with VGG19 content +
+              adversarial loss, Adam for both), batch 32 per GPU, LR 128x128 -> HR 512x512, bf16 storage / fp32 accumulate.
+  gen_l1_x4 : BASELINE config 2 -- generator-only L1 step, batch 16, 32x32 -> 128x128.
+N > 1: one process per GPU (torchrun), batch sharded data-parallel (weak scaling: fixed per-GPU batch), gradients
+averaged with RCCL all-reduce.  Rank 0 prints ONE JSON line.
+
+Extra legs (rank 0, N = 1 only):
+  roofline     : one more, un-timed-for-throughput step is run with every convolution launch bracketed by HIP events
+                 on its own stream; for the kernel family with the largest total time it reports algorithmic
+                 FLOP/s = sum of 2*M*Cout*KH*KW*Cin over its launches / sum of their durations, against the dense
+                 bf16 MFMA peak (2.5 PFLOP/s).
+  cpu_baseline : the CPU oracle (oracle/, a PyTorch fp32 restatement pinned to the reference) timed on the host cores
+                 on a bounded sample of the same workload.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PKG = "deep-super-resolution_amd"
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def P(sub):
+    return importlib.import_module(PKG + "." + sub)
+
+
+WORKLOADS = {
+    # name: (batch per GPU, LR size, factor, description)
+    "gan_x4": dict(batch=32, lr=128, factor=4, desc="full GAN step x4 (G + D + VGG19 perceptual), batch 32/GPU, 128x128->512x512"),
+    "gen_l1_x4": dict(batch=16, lr=32, factor=4, desc="generator-only L1 step x4, batch 16/GPU, 32x32->128x128"),
+}
+
+
+def conv_flops(d):
+    n, h, w, cin, cout, kh, kw, stride, pad = d
+    oh, ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    return 2.0 * n * oh * ow * cout * kh * kw * cin
+
+
+def kernel_family(kind, d):
+    cout, cin = d[4], d[3]
+    if kind == "wgrad":
+        return "conv_wgrad_kernel"
+    nb = cin if kind == "dgrad" else cout          # output-column count of the GEMM
+    tile = "128x128" if nb > 64 else ("128x64" if nb > 16 else "128x16")
+    return f"conv_gemm_kernel<{tile}>"
+
+
+def build_step(workload, dev, world):
+    cfg = WORKLOADS[workload]
+    Gm, optim, steps = P("models.GAN.generator"), P("optim"), P("steps")
+    torch.manual_seed(0)                      # module-default init under seed 0
+    gen = Gm.Generator(cfg["factor"], 16).to(dev).train()
+    n, s, f = cfg["batch"], cfg["lr"], cfg["factor"]
+    g = torch.Generator(device="cpu").manual_seed(1 + (dist.get_rank() if world > 1 else 0))
+    lr = torch.rand(n, 3, s, s, generator=g).to(dev)                     # LR ~ U(0,1)
+    hr = (torch.rand(n, 3, s * f, s * f, generator=g) * 2 - 1).to(dev)   # HR ~ U(-1,1)
+    D = P("dist")
+    opt_g = optim.FusedAdam(gen.parameters(), lr=1e-4)
+    sync_g = D.GradSync(gen.parameters())
+    if workload == "gen_l1_x4":
+        D.broadcast_module(gen)
+        F = P("functional")
+
+        def step():
+            fake = gen(lr)
+            loss = F.l1_loss(fake, hr)
+            opt_g.zero_grad()
+            loss.backward()
+            sync_g()
+            opt_g.step()
+            return loss
+        return step, n * (s * f) ** 2
+    Dm, GANu = P("models.GAN.discriminator"), P("utils.GAN")
+    F = P("functional")
+    disc = Dm.Discriminator((s * f, s * f)).to(dev).train()
+    perc = GANu.PerceptualLoss().to(dev)
+    D.broadcast_module(gen)
+    D.broadcast_module(disc)
+    opt_d = optim.FusedAdam(disc.parameters(), lr=1e-4)
+    sync_d = D.GradSync(disc.parameters())
+
+    def step():
+        real_d = disc(hr)                                           # train_GAN.py:44
+        fake = gen(lr).detach()                                     # :46
+        fake_d = disc(fake)                                         # :47
+        loss_d = F.bce_const(real_d, 1.0) + F.bce_const(fake_d, 0.0)
+        opt_d.zero_grad()
+        loss_d.backward()
+        sync_d()
+        opt_d.step()
+        fake = gen(lr)                                              # :56
+        with torch.no_grad():
+            fake_d = disc(fake.detach())                            # :58
+        loss_g = perc(fake, hr, fake_d, None)                       # :59
+        opt_g.zero_grad()
+        loss_g.backward()
+        sync_g()
+        opt_g.step()
+        return loss_g
+    return step, n * (s * f) ** 2
+
+
+def host_cores():
+    """Cores this process may actually use: affinity mask, clipped by the cgroup CPU quota (the GPU box gives one
+    GPU's share of a large host; os.cpu_count() would oversubscribe it by an order of magnitude)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(workload):
+    """The oracle (CPU fp32 restatement of the reference) on a bounded sample of the same workload."""
+    from oracle import filler, gan, recipes, vgg
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    cfg = WORKLOADS[workload]
+    f = cfg["factor"]
+    torch.manual_seed(0)
+    gsd = filler.fill_state_dict(gan.template(gan.generator_shapes(f, 16)))
+    if workload == "gen_l1_x4":
+        n, s, reps = cfg["batch"], cfg["lr"], 3
+        st = recipes.GenOnlyState(gsd, lr=1e-4)
+        lr, hr = torch.rand(n, 3, s, s), torch.rand(n, 3, s * f, s * f) * 2 - 1
+        recipes.gen_l1_step(st, lr, hr)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            recipes.gen_l1_step(st, lr, hr)
+        dt = (time.perf_counter() - t0) / reps
+        sample = f"{reps} full steps (batch {n}, {s}x{s}->{s*f}x{s*f}) after 1 warm-up"
+    else:
+        n, s, reps = 1, cfg["lr"], 1      # one sample of the batch-32 step: per-sample cost scales linearly in batch
+        dsd = filler.fill_state_dict(gan.template(gan.discriminator_shapes((s * f, s * f))))
+        vsd = filler.fill_state_dict({k: torch.zeros(v) for k, v in vgg.vgg_shapes().items()}, salt=3)
+        st = recipes.GanState(gsd, dsd, vsd, lr=1e-4)
+        lr, hr = torch.rand(n, 3, s, s), torch.rand(n, 3, s * f, s * f) * 2 - 1
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            recipes.gan_step(st, lr, hr)
+        dt = (time.perf_counter() - t0) / reps
+        sample = f"{reps} step at batch {n} of the batch-{cfg['batch']} workload ({s}x{s}->{s*f}x{s*f}), no warm-up"
+    px = n * (s * f) ** 2
+    return {"value": px / dt / 1e6, "unit": "HR Mpixels/s", "cores": cores, "kind": "port", "sample": sample,
+            "seconds_per_step": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="gan_x4", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    P("_lib").lib()
+
+    step, px_per_rank = build_step(a.workload, dev, world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"workload {a.workload}, world {world}: warm-up")
+    for _ in range(a.warmup):
+        step()
+    fence()
+    note("timed region")
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / a.steps * 1e3
+    value = px_per_rank * world * a.steps / dt / 1e6
+
+    out = {"metric": "HR Mpixels/sec x4 GAN train step", "value": value, "unit": "HR Mpixels/s", "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": a.workload + ": " + WORKLOADS[a.workload]["desc"],
+                      "global_batch": WORKLOADS[a.workload]["batch"] * world, "parallelism": f"dp{world}"}}
+
+    note(f"{ms:.2f} ms/step")
+    if rank == 0 and world == 1 and not a.no_roofline:
+        note("roofline leg")
+        F = P("functional")
+        F.KERNEL_LOG = []
+        step()
+        torch.cuda.synchronize()
+        fam = {}
+        for kind, d, e0, e1 in F.KERNEL_LOG:
+            k = kernel_family(kind, d)
+            t, fl, cnt = fam.get(k, (0.0, 0.0, 0))
+            fam[k] = (t + e0.elapsed_time(e1) * 1e-3, fl + conv_flops(d), cnt + 1)
+        F.KERNEL_LOG = None
+        if fam:
+            top = max(fam, key=lambda k: fam[k][0])
+            t, fl, cnt = fam[top]
+            ach = fl / t / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": top, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "launches": cnt, "avg_launch_ms": t / cnt * 1e3,
+                               "families": {k: {"seconds": v[0], "tflops": v[1] / v[0] / 1e12, "launches": v[2]}
+                                            for k, v in fam.items()}}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        note("cpu baseline (oracle on host cores)")
+        out["cpu_baseline"] = cpu_baseline(a.workload)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,7 +44,8 @@ SIGNATURES = {
     "dsr_pw_nchw_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dsr_pw_nhwc_to_nchw": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dsr_pw_pack_weight": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "dsr_pw_sum_rows": (_I, [_P, _I, _I, _I, _F, _P, _I, _P]),
+    "dsr_pw_scratch_rows": (_I, []),
+    "dsr_pw_sum_rows": (_I, [_P, _I, _I, _I, _I, _F, _P, _I, _I, _P]),
     "dsr_pw_bn_finalize": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P]),
     "dsr_pw_bn_eval_affine": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P]),
     "dsr_pw_reduce_blocks": (_I, [_Z, C.POINTER(_I)]),
@@ -59,7 +60,7 @@ SIGNATURES = {
     "dsr_pw_add": (_I, [_I, _P, _P, _P, _Z, _P]),
     "dsr_pw_diff_loss": (_I, [_P, _P, _P, _Z, _I, _P, _I, _P]),
     "dsr_pw_bce_const": (_I, [_P, _I, _F, _P, _P, _I, _P]),
-    "dsr_pw_adam": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P, _P]),
+    "dsr_pw_adam": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P, _F, _P]),
     "dsr_pw_incr": (_I, [_P, _P]),
     "dsr_cast16": (_I, [_I, _P, _P, _Z, _P]),
     "dsr_flatten": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -72,14 +72,50 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, unsigned short* 
   }
 }
 
+// ------------------------------------------------------------------ parallel compaction of partial rows
+// in: [rows][width] fp32 partial sums  ->  out: [nchunks][width], out[c] = sum of rows [c*rpc, (c+1)*rpc).
+// 64 columns x 4 row-lanes per block; fixed summation order => deterministic.  The finalize kernels below then
+// walk <= DSR_COMPACT_ROWS rows instead of up to 65,536 (one per conv M-tile).
+#define DSR_COMPACT_ROWS 64
+__global__ __launch_bounds__(256) void compact_rows_kernel(const float* __restrict__ in, int rows, int width, int rpc,
+                                                           float* __restrict__ out) {
+  __shared__ double red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const int r0 = blockIdx.y * rpc;
+  int r1 = r0 + rpc;
+  if (r1 > rows) r1 = rows;
+  double s = 0.0;
+  if (col < width)
+    for (int r = r0 + ry; r < r1; r += 4) s += (double)in[(size_t)r * width + col];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < width) out[(size_t)blockIdx.y * width + col] = (float)(red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
+}
+
+// returns the number of rows left (and the pointer to use); scratch = `partial + rows*width` (caller reserves
+// DSR_COMPACT_ROWS extra rows behind every partial buffer, see dsr_pw_scratch_rows()).
+static const float* compact_rows(const float* partial, int rows, int width, int* rows_out, hipStream_t st) {
+  if (rows <= 4 * DSR_COMPACT_ROWS) {
+    *rows_out = rows;
+    return partial;
+  }
+  int rpc = (rows + DSR_COMPACT_ROWS - 1) / DSR_COMPACT_ROWS;
+  int nch = (rows + rpc - 1) / rpc;
+  float* out = const_cast<float*>(partial) + (size_t)rows * width;
+  hipLaunchKernelGGL(compact_rows_kernel, dim3((width + 63) / 64, nch), dim3(256), 0, st, partial, rows, width, rpc, out);
+  *rows_out = nch;
+  return out;
+}
+
 // ------------------------------------------------------------------ generic partial-row sum
 // out[c] = sum_b partial[b*stride_b + c]   (fp64 accumulate), optional scale
-__global__ void sum_rows_kernel(const float* __restrict__ partial, int rows, int row_stride, int C, float scale,
-                                float* __restrict__ out, int accumulate) {
+__global__ void sum_rows_kernel(const float* __restrict__ partial, int rows, int row_stride, int col_offset, int C,
+                                float scale, float* __restrict__ out, int accumulate) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0.0;
-  for (int b = 0; b < rows; ++b) s += (double)partial[(size_t)b * row_stride + c];
+  for (int b = 0; b < rows; ++b) s += (double)partial[(size_t)b * row_stride + col_offset + c];
   float v = (float)(s * (double)scale);
   out[c] = accumulate ? out[c] + v : v;
 }
@@ -538,13 +574,13 @@ __global__ void bce_const_kernel(const float* __restrict__ p, int n, float targe
 // step counter lives on the device so the launch is graph-capturable.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
-                            const int* __restrict__ step) {
+                            const int* __restrict__ step, float grad_scale) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int t = *step;
   float bc1 = 1.f - powf(b1, (float)t);
   float bc2 = 1.f - powf(b2, (float)t);
-  float gi = g[i];
+  float gi = g[i] * grad_scale;   // 1/S un-does a static loss scale (fp16 storage); 1 otherwise
   float mi = b1 * m[i] + (1.f - b1) * gi;
   float vi = b2 * v[i] + (1.f - b2) * gi * gi;
   m[i] = mi;
@@ -586,16 +622,19 @@ extern "C" int dsr_pw_pack_weight(int dtype, const float* w, void* wf, void* wd,
                                       (unsigned short*)wf, (unsigned short*)wd, Cout, Cin, T, NBo, CinP, NBi, CoutP));
   return dsr_launch_status("dsr_pw_pack_weight");
 }
-extern "C" int dsr_pw_sum_rows(const float* partial, int rows, int row_stride, int C, float scale, float* out, int accumulate,
-                     hipStream_t st) {
-  hipLaunchKernelGGL(sum_rows_kernel, dim3(nblk(C, 128)), dim3(128), 0, st, partial, rows, row_stride, C, scale, out,
-                     accumulate);
+extern "C" int dsr_pw_scratch_rows(void) { return DSR_COMPACT_ROWS; }
+extern "C" int dsr_pw_sum_rows(const float* partial, int rows, int row_stride, int col_offset, int C, float scale, float* out,
+                     int accumulate, int compact, hipStream_t st) {
+  if (compact && row_stride > 1) partial = compact_rows(partial, rows, row_stride, &rows, st);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(nblk(C, 128)), dim3(128), 0, st, partial, rows, row_stride, col_offset, C,
+                     scale, out, accumulate);
   return dsr_launch_status("dsr_pw_sum_rows");
 }
 extern "C" int dsr_pw_bn_finalize(const float* partial, int tiles, int stride, int C, int Cp, float count, const float* gamma,
                         const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, int updates,
                         float* scale, float* shift, float* mean, float* rstd, hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(Cp, 128)), dim3(128), 0, st, partial, tiles, stride, C, count, gamma,
+  partial = compact_rows(partial, tiles, 2 * stride, &tiles, st);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(Cp, 64)), dim3(64), 0, st, partial, tiles, stride, C, count, gamma,
                      beta, rm, rv, nbt, momentum, eps, updates, scale, shift, mean, rstd, Cp);
   return dsr_launch_status("dsr_pw_bn_finalize");
 }
@@ -637,6 +676,7 @@ extern "C" int dsr_pw_bn_act_bwd_reduce(int dtype, const void* dout, const void*
 }
 extern "C" int dsr_pw_bn_bwd_finalize(const float* partial, int blocks, int C, int Cp, float count, float* dgamma, float* dbeta,
                             float* dprelu, float* c1, float* c2, hipStream_t st) {
+  partial = compact_rows(partial, blocks, 3 * Cp, &blocks, st);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, blocks, C, Cp, count, dgamma, dbeta,
                      dprelu, c1, c2);
   return dsr_launch_status("dsr_pw_bn_bwd_finalize");
@@ -686,8 +726,8 @@ extern "C" int dsr_pw_bce_const(const float* p, int n, float target, float* loss
   return dsr_launch_status("dsr_pw_bce_const");
 }
 extern "C" int dsr_pw_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-                 const int* step, hipStream_t st) {
-  hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, step);
+                 const int* step, float grad_scale, hipStream_t st) {
+  hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, step, grad_scale);
   return dsr_launch_status("dsr_pw_adam");
 }
 extern "C" int dsr_pw_incr(int* step, hipStream_t st) {

@@ -9,6 +9,7 @@ PyTorch is only plumbing here: it owns device memory, the stream and the autogra
 FLOP is a HIP kernel from csrc/.  Nothing in this file can run without the extension.
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -46,6 +47,22 @@ def _need_gpu(t):
                            "there is no CPU implementation of this path")
 
 
+# ----------------------------------------------------------------------------- per-launch timing (bench.py roofline leg)
+KERNEL_LOG = None          # set to a list to record (kind, desc-tuple, start_event, end_event) per conv launch
+
+
+def _timed(kind, desc, fn):
+    """Run one C-ABI conv call; when KERNEL_LOG is a list, bracket it with HIP events on the launch stream."""
+    if KERNEL_LOG is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn()
+    e1.record()
+    KERNEL_LOG.append((kind, (desc.N, desc.H, desc.W, desc.Cin, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad), e0, e1))
+    return rc
+
+
 # ----------------------------------------------------------------------------- weight images
 _pack_cache = {}
 
@@ -65,10 +82,11 @@ def clear_pack_cache():
 
 def packed_weights(weight, desc, dtype):
     """16-bit [T][Cout_p][Cin_p] (forward) and [T][Cin_p][Cout_p] (dgrad) images of an OIHW fp32 weight."""
-    key = (id(weight), dtype, desc.KH, desc.KW)
+    key = (id(weight), dtype, tuple(weight.shape))
     ver = _version(weight)
     hit = _pack_cache.get(key)
-    if hit is not None and hit[0] == ver:
+    # ids (and allocator addresses) are recycled once a tensor dies: a hit must be THIS tensor object
+    if hit is not None and hit[0] == ver and hit[3]() is weight:
         return hit[1], hit[2]
     lib = _lib.lib()
     nf = lib.dsr_conv_packed_elems(C.byref(desc), 0)
@@ -79,7 +97,10 @@ def packed_weights(weight, desc, dtype):
     if not w.is_contiguous():
         w = w.contiguous()
     check(lib.dsr_conv_pack_weight(C.byref(desc), _ptr(w), _ptr(wf), _ptr(wd), _stream()))
-    _pack_cache[key] = (ver, wf, wd)
+    _pack_cache[key] = (ver, wf, wd, weakref.ref(weight))
+    if len(_pack_cache) > 4096:          # dead entries of short-lived tensors (tests); live models are far smaller
+        for k in [k for k, v in _pack_cache.items() if v[3]() is None]:
+            del _pack_cache[k]
     return wf, wd
 
 
@@ -95,6 +116,10 @@ def _out_hw(desc):
     return oh.value, ow.value
 
 
+def _scr():
+    return _lib.lib().dsr_pw_scratch_rows()
+
+
 def _reduce_blocks(p):
     rpb = C.c_int()
     blocks = _lib.lib().dsr_pw_reduce_blocks(p, C.byref(rpb))
@@ -108,12 +133,14 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape):
         dx = torch.empty_like(x)
         wsz = lib.dsr_conv_dgrad_workspace(C.byref(desc))
         ws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=x.device)
-        check(lib.dsr_conv_dgrad(C.byref(desc), _ptr(dy), _ptr(wd), _ptr(dx), _ptr(ws), wsz, _stream()))
+        check(_timed("dgrad", desc, lambda: lib.dsr_conv_dgrad(C.byref(desc), _ptr(dy), _ptr(wd), _ptr(dx), _ptr(ws), wsz,
+                                                                 _stream())))
     if need_dw:
         dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
         wsz = lib.dsr_conv_wgrad_workspace(C.byref(desc))
         ws = torch.empty(wsz, dtype=torch.uint8, device=x.device)
-        check(lib.dsr_conv_wgrad(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), wsz, _stream()))
+        check(_timed("wgrad", desc, lambda: lib.dsr_conv_wgrad(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), wsz,
+                                                                 _stream())))
     return dx, dw
 
 
@@ -123,10 +150,10 @@ def _colsum(dy, c):
     p = dy.numel() // dy.shape[-1]
     cp = dy.shape[-1]
     blocks, rpb = _reduce_blocks(p)
-    part = torch.empty(blocks * cp, dtype=torch.float32, device=dy.device)
+    part = torch.empty((blocks + _scr()) * cp, dtype=torch.float32, device=dy.device)
     check(lib.dsr_pw_colsum(_dt(dy), _ptr(dy), p, cp, blocks, rpb, _ptr(part), _stream()))
     out = torch.empty(c, dtype=torch.float32, device=dy.device)
-    check(lib.dsr_pw_sum_rows(_ptr(part), blocks, cp, c, 1.0, _ptr(out), 0, _stream()))
+    check(lib.dsr_pw_sum_rows(_ptr(part), blocks, cp, 0, c, 1.0, _ptr(out), 0, 1, _stream()))
     return out
 
 
@@ -199,7 +226,8 @@ class ConvAct(torch.autograd.Function):
             y = torch.empty((n, oh, ow, r8(cout)), dtype=x.dtype, device=x.device)
         act = cfg.get("act", ACT_NONE)
         ep = Epilogue(act, float(cfg.get("slope", 0.0)), _ptr(prelu), _ptr(bias), None, int(ps), None)
-        check(_lib.lib().dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y), _stream()))
+        check(_timed("fwd", desc, lambda: _lib.lib().dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y),
+                                                                    _stream())))
         ctx.desc, ctx.cfg, ctx.ps, ctx.act = desc, cfg, ps, act
         ctx.wshape = tuple(weight.shape)
         ctx.has_bias = bias is not None
@@ -226,19 +254,19 @@ class ConvAct(torch.autograd.Function):
             dy = torch.empty((n, oh, ow, cyp), dtype=x.dtype, device=x.device)
             p = n * oh * ow
             blocks, rpb = _reduce_blocks(p)
-            part = torch.empty(blocks * 2 * cyp, dtype=torch.float32, device=x.device) if need_partial else None
+            part = torch.empty((blocks + _scr()) * 2 * cyp, dtype=torch.float32, device=x.device) if need_partial else None
             check(lib.dsr_pw_act_bwd(_dt(x), _ptr(dout), _ptr(y), _ptr(dy), n, oh, ow, cyp, y.shape[-1], int(ctx.ps),
                                      ctx.act, float(ctx.cfg.get("slope", 0.0)), _ptr(prelu), blocks, rpb, _ptr(part),
                                      _stream()))
             db = dprelu = None
             if ctx.has_bias:
                 db = torch.empty(cout, dtype=torch.float32, device=x.device)
-                check(lib.dsr_pw_sum_rows(_ptr(part), blocks, 2 * cyp, cout, 1.0, _ptr(db), 0, _stream()))
+                check(lib.dsr_pw_sum_rows(_ptr(part), blocks, 2 * cyp, 0, cout, 1.0, _ptr(db), 0, 1, _stream()))
             if prelu is not None:
                 chan = torch.empty(cyp, dtype=torch.float32, device=x.device)
-                check(lib.dsr_pw_sum_rows(_ptr(part[cyp:]), blocks, 2 * cyp, cyp, 1.0, _ptr(chan), 0, _stream()))
+                check(lib.dsr_pw_sum_rows(_ptr(part), blocks, 2 * cyp, cyp, cyp, 1.0, _ptr(chan), 0, 1, _stream()))
                 dprelu = torch.empty(1, dtype=torch.float32, device=x.device)
-                check(lib.dsr_pw_sum_rows(_ptr(chan), cyp, 1, 1, 1.0, _ptr(dprelu), 0, _stream()))
+                check(lib.dsr_pw_sum_rows(_ptr(chan), cyp, 1, 0, 1, 1.0, _ptr(dprelu), 0, 0, _stream()))
         dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape)
         return dx, dw, db, dprelu, None
 
@@ -274,15 +302,17 @@ class ConvBNAct(torch.autograd.Function):
         count = n * oh * ow
         if train:
             rows = lib.dsr_conv_stats_rows(C.byref(desc))
-            part = torch.empty(rows * 2 * cp, dtype=torch.float32, device=dev)
+            part = torch.empty((rows + _scr()) * 2 * cp, dtype=torch.float32, device=dev)
             ep = Epilogue(ACT_NONE, 0.0, None, _ptr(bias), _ptr(part), 0, None)
-            check(lib.dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y), _stream()))
+            check(_timed("fwd", desc, lambda: lib.dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y),
+                                                                 _stream())))
             check(lib.dsr_pw_bn_finalize(_ptr(part), rows, cp, cout, cp, float(count), _ptr(gamma), _ptr(beta),
                                          _ptr(running_mean), _ptr(running_var), _ptr(nbt), BN_MOMENTUM, BN_EPS, 1,
                                          _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
         else:
             ep = Epilogue(ACT_NONE, 0.0, None, _ptr(bias), None, 0, None)
-            check(lib.dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y), _stream()))
+            check(_timed("fwd", desc, lambda: lib.dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y),
+                                                                 _stream())))
             check(lib.dsr_pw_bn_eval_affine(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), BN_EPS,
                                             cout, cp, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
         act = cfg.get("act", ACT_NONE)
@@ -316,7 +346,7 @@ class ConvBNAct(torch.autograd.Function):
         dbeta = torch.empty(cout, dtype=torch.float32, device=dev)
         dprelu = torch.empty(1, dtype=torch.float32, device=dev) if prelu is not None else None
         blocks, rpb = _reduce_blocks(p)
-        part = torch.empty(blocks * 3 * cp, dtype=torch.float32, device=dev)
+        part = torch.empty((blocks + _scr()) * 3 * cp, dtype=torch.float32, device=dev)
         check(lib.dsr_pw_bn_act_bwd_reduce(_dt(x), _ptr(dout), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean),
                                            _ptr(rstd), p, cp, blocks, rpb, ctx.act, slope, _ptr(prelu), _ptr(part),
                                            _stream()))
@@ -351,7 +381,8 @@ class ConvOutNCHW(torch.autograd.Function):
         out = torch.empty((x.shape[0], cout, oh, ow), dtype=torch.float32, device=x.device)
         act = cfg.get("act", ACT_NONE)
         ep = Epilogue(act, 0.0, None, _ptr(bias), None, 0, _ptr(out))
-        check(_lib.lib().dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), None, _stream()))
+        check(_timed("fwd", desc, lambda: _lib.lib().dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), None,
+                                                                    _stream())))
         ctx.desc, ctx.act = desc, act
         ctx.wshape = tuple(weight.shape)
         ctx.has_bias = bias is not None
@@ -389,7 +420,7 @@ class DiffLoss(torch.autograd.Function):
         lib = _lib.lib()
         check(lib.dsr_pw_diff_loss(_ptr(pred), _ptr(target), _ptr(grad), n, mode, _ptr(part), blocks, _stream()))
         loss = torch.empty(1, dtype=torch.float32, device=pred.device)
-        check(lib.dsr_pw_sum_rows(_ptr(part), blocks, 1, 1, 1.0 / n, _ptr(loss), 0, _stream()))
+        check(lib.dsr_pw_sum_rows(_ptr(part), blocks, 1, 0, 1, 1.0 / n, _ptr(loss), 0, 0, _stream()))
         ctx.save_for_backward(grad)
         return loss.reshape(())
 
@@ -436,15 +467,16 @@ _shadow_cache = {}
 
 def shadow16(weight, dtype):
     """16-bit copy of an fp32 matrix in its own layout, refreshed when the parameter changes."""
-    key = (id(weight), dtype)
+    key = (id(weight), dtype, tuple(weight.shape))
     ver = _version(weight)
     hit = _shadow_cache.get(key)
-    if hit is not None and hit[0] == ver:
+    same = hit is not None and hit[2]() is weight
+    if same and hit[0] == ver:
         return hit[1]
     w = weight.detach().contiguous()
-    out = hit[1] if hit is not None and hit[1].numel() == w.numel() else torch.empty(w.shape, dtype=dtype, device=w.device)
+    out = hit[1] if same else torch.empty(w.shape, dtype=dtype, device=w.device)
     check(_lib.lib().dsr_cast16(_dt(out), _ptr(w), _ptr(out), w.numel(), _stream()))
-    _shadow_cache[key] = (ver, out)
+    _shadow_cache[key] = (ver, out, weakref.ref(weight))
     return out
 
 
@@ -644,7 +676,7 @@ class BNAct(torch.autograd.Function):
         rstd = torch.empty(cp, dtype=torch.float32, device=dev)
         if train:
             blocks, rpb = _reduce_blocks(p)
-            part = torch.empty(blocks * 2 * cp, dtype=torch.float32, device=dev)
+            part = torch.empty((blocks + _scr()) * 2 * cp, dtype=torch.float32, device=dev)
             check(lib.dsr_pw_channel_stats(_dt(x), _ptr(x), p, cp, blocks, rpb, _ptr(part), _stream()))
             check(lib.dsr_pw_bn_finalize(_ptr(part), blocks, cp, c, cp, float(p), _ptr(gamma), _ptr(beta),
                                          _ptr(running_mean), _ptr(running_var), _ptr(nbt), BN_MOMENTUM, BN_EPS, 1,
@@ -674,7 +706,7 @@ class BNAct(torch.autograd.Function):
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
         blocks, rpb = _reduce_blocks(p)
-        part = torch.empty(blocks * 3 * cp, dtype=torch.float32, device=dev)
+        part = torch.empty((blocks + _scr()) * 3 * cp, dtype=torch.float32, device=dev)
         check(lib.dsr_pw_bn_act_bwd_reduce(_dt(x), _ptr(dout), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
                                            p, cp, blocks, rpb, ctx.act, slope, None, _ptr(part), _stream()))
         check(lib.dsr_pw_bn_bwd_finalize(_ptr(part), blocks, c, cp, float(p), _ptr(dgamma), _ptr(dbeta), None, _ptr(c1),

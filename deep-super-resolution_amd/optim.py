@@ -10,11 +10,12 @@ from .functional import _ptr, _stream, bump, check
 
 
 class FusedAdam:
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
         self.params = [p for p in params]
         if not self.params:
             raise ValueError("optimizer got an empty parameter list")   # torch.optim raises the same
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        self.grad_scale = float(grad_scale)     # gradients are multiplied by this first (1/S for a loss scale S)
         dev = self.params[0].device
         self.m = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
         self.v = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
@@ -38,5 +39,5 @@ class FusedAdam:
             if g.dtype != torch.float32 or not g.is_contiguous():
                 g = g.float().contiguous()
             check(lib.dsr_pw_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), self.lr, self.betas[0], self.betas[1],
-                                  self.eps, _ptr(self.step_t), st))
+                                  self.eps, _ptr(self.step_t), self.grad_scale, st))
             bump(p)

@@ -44,15 +44,21 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches):
 class DipRunner:
     """DIP.py:22-123 state: fixed noise input, jitter buffer, Lanczos downsampler, Adam over the net."""
 
-    def __init__(self, net, downsampler, net_input, lr_image, learning_rate, reg_noise_std):
+    def __init__(self, net, downsampler, net_input, lr_image, learning_rate, reg_noise_std, loss_scale=None):
         from .optim import FusedAdam
+        # fp16 storage (the DIP default, see models/DIP/skip.py) needs a static loss scale so that activation
+        # gradients (~1e-5 at the MSE) stay out of fp16's subnormal range; Adam un-scales on the fly.
+        if loss_scale is None:
+            loss_scale = 1024.0 if getattr(net, "compute_dtype", None) == torch.float16 else 1.0
+        self.loss_scale = float(loss_scale)
         self.net, self.down = net, downsampler
         self.net_input_saved = net_input.detach().clone()        # DIP.py:33
         self.noise = net_input.detach().clone()                  # DIP.py:34
         self.net_input = net_input
         self.lr_image = lr_image
         self.sigma = reg_noise_std
-        self.opt = FusedAdam(list(net.parameters()), lr=learning_rate)   # get_params('net') + utils/DIP.py:34
+        self.opt = FusedAdam(list(net.parameters()), lr=learning_rate,
+                             grad_scale=1.0 / self.loss_scale)       # get_params('net') + utils/DIP.py:34
 
     def step(self, noise=None):
         """optimizer.zero_grad(); closure(); optimizer.step()  (utils/DIP.py:35-38, DIP.py:47-68)."""
@@ -64,6 +70,6 @@ class DipRunner:
         out_hr = self.net(self.net_input)                        # :60
         out_lr = self.down(out_hr)                               # :62
         loss = F.mse_loss(out_lr, self.lr_image)                 # :65
-        loss.backward()                                          # :68
+        (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()   # :68
         self.opt.step()
         return loss.detach(), out_hr.detach()

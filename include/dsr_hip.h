@@ -89,8 +89,14 @@ int dsr_pw_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, in
 int dsr_pw_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int H, int W, int Cp, dsr_stream_t s);
 int dsr_pw_pack_weight(int dtype, const float* w, void* wf, void* wd, int Cout, int Cin, int T, int NBo, int CinP,
                        int NBi, int CoutP, dsr_stream_t s);
-int dsr_pw_sum_rows(const float* partial, int rows, int row_stride, int C, float scale, float* out, int accumulate,
-                    dsr_stream_t s);
+/* Two-stage deterministic reductions: kernels write one partial ROW per block; the finalize entry points first
+ * compact many rows in parallel into <= dsr_pw_scratch_rows() rows stored right behind the partial buffer, so EVERY
+ * partial buffer handed to dsr_pw_bn_finalize / dsr_pw_bn_bwd_finalize / dsr_pw_sum_rows(compact=1) must have room
+ * for `rows + dsr_pw_scratch_rows()` rows. */
+int dsr_pw_scratch_rows(void);
+/* out[c] (+)= scale * sum_r partial[r*row_stride + col_offset + c], c < C */
+int dsr_pw_sum_rows(const float* partial, int rows, int row_stride, int col_offset, int C, float scale, float* out,
+                    int accumulate, int compact, dsr_stream_t s);
 int dsr_pw_bn_finalize(const float* partial, int tiles, int stride, int C, int Cp, float count, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
                        float momentum, float eps, int updates, float* scale, float* shift, float* mean, float* rstd,
@@ -122,8 +128,9 @@ int dsr_pw_add(int dtype, const void* a, const void* b, void* out, size_t nvec, 
 int dsr_pw_diff_loss(const float* pred, const float* tgt, float* grad, size_t n, int mode, float* partial, int blocks,
                      dsr_stream_t s);
 int dsr_pw_bce_const(const float* p, int n, float target, float* loss, float* grad, int accumulate, dsr_stream_t s);
+/* torch.optim.Adam defaults; g is multiplied by grad_scale first (1/S when a static loss scale S is in use) */
 int dsr_pw_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-                const int* step, dsr_stream_t s);
+                const int* step, float grad_scale, dsr_stream_t s);
 int dsr_pw_incr(int* step, dsr_stream_t s);
 
 /* ------------------------------------------------------------------ discriminator dense head (linear.hip)

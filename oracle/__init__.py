@@ -16,4 +16,4 @@ Pieces of the path that live in third-party packages that are absent here
 (torchvision's VGG19 weights + ``ImageClassification`` preset, torchmetrics PSNR) are
 restated from their published definitions and marked "parity unpinned" in place.
 """
-from . import filler, gan, dip, downsampler, losses, vgg, recipes  # noqa: F401
+from . import filler, gan, dip, downsampler, losses, lowp, vgg, recipes  # noqa: F401

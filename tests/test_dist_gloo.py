@@ -1,0 +1,68 @@
+"""CPU, world_size 2, gloo: the data-parallel gradient averaging (deep-super-resolution_amd/dist.py) gives every
+rank the mean of the per-rank gradients, for bucketed small tensors and in-place big ones alike, and is a no-op
+when torch.distributed is not initialised."""
+import importlib
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = "deep-super-resolution_amd"
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    D = importlib.import_module(PKG + ".dist")
+    torch.manual_seed(0)
+    shapes = [(64, 64, 3, 3), (64,), (1,), (1024, 300), (3, 64, 9, 9)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    ref = []
+    for i, p in enumerate(params):
+        per_rank = [torch.full(p.shape, float(r + 1)) * (i + 1) + torch.arange(p.numel()).reshape(p.shape) * 1e-3 * (r + 1)
+                    for r in range(world)]
+        p.grad = per_rank[rank].clone()
+        ref.append(sum(per_rank) / world)
+    sync = D.GradSync(params, bucket_bytes=100_000, big_bytes=1_000_000)     # (1024,300) fp32 = 1.2 MB -> "big" path
+    sync()
+    ok = all(torch.allclose(p.grad, r, rtol=1e-6, atol=1e-6) for p, r in zip(params, ref))
+    # broadcast_module: rank 1 starts from garbage and must end with rank 0's values
+    lin = torch.nn.Linear(4, 3)
+    if rank == 1:
+        with torch.no_grad():
+            for t in lin.parameters():
+                t.fill_(123.0)
+    D.broadcast_module(lin)
+    w = lin.weight.detach().clone()
+    gathered = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(gathered, w)
+    ok = ok and torch.equal(gathered[0], gathered[1])
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_grad_sync_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_grad_sync_noop_single_process():
+    sys.path.insert(0, ROOT)
+    D = importlib.import_module(PKG + ".dist")
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.grad = torch.ones(3)
+    D.GradSync([p])()
+    assert torch.equal(p.grad, torch.ones(3)) and not D.is_dist()
