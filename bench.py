@@ -96,23 +96,7 @@ def build_step(workload, dev, world):
     sync_d = D.GradSync(disc.parameters())
 
     def step():
-        real_d = disc(hr)                                           # train_GAN.py:44
-        fake = gen(lr).detach()                                     # :46
-        fake_d = disc(fake)                                         # :47
-        loss_d = F.bce_const(real_d, 1.0) + F.bce_const(fake_d, 0.0)
-        opt_d.zero_grad()
-        loss_d.backward()
-        sync_d()
-        opt_d.step()
-        fake = gen(lr)                                              # :56
-        with torch.no_grad():
-            fake_d = disc(fake.detach())                            # :58
-        loss_g = perc(fake, hr, fake_d, None)                       # :59
-        opt_g.zero_grad()
-        loss_g.backward()
-        sync_g()
-        opt_g.step()
-        return loss_g
+        return steps.gan_step(gen, disc, perc, opt_g, opt_d, lr, hr, sync_g, sync_d)[1]
     return step, n * (s * f) ** 2
 
 

@@ -82,6 +82,7 @@ static void finish_args(ConvGemmArgs& a) {
   a.fd_ghw = fd_make((unsigned)(a.GH * a.GW));
   a.fd_gw = fd_make((unsigned)a.GW);
   a.fd_cu = fd_make((unsigned)a.CU);
+  a.fd_cu8 = fd_make((unsigned)((a.CU >> 3) > 0 ? (a.CU >> 3) : 1));
 }
 
 extern "C" int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w_fwd, const dsr_epilogue* e, void* y,
@@ -129,6 +130,32 @@ extern "C" int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w
     a.OH = OH;
     a.OW = OW;
     a.CoutP = r8(d->Cout);
+  }
+  if (d->Cout <= 16 && d->stride == 1 && d->pad_mode == DSR_PAD_ZERO && d->KH * d->KW >= 9 && !e->stats_partial &&
+      !e->pixel_shuffle) {
+    // few output channels + many taps: stage the input halo once instead of gathering it once per tap
+    SmallNArgs sn;
+    memset(&sn, 0, sizeof(sn));
+    sn.x = x;
+    sn.w = w_fwd;
+    sn.y = y;
+    sn.out_f32 = e->out_nchw_f32;
+    sn.bias = e->bias;
+    sn.prelu = (e->act == DSR_ACT_PRELU) ? e->prelu : nullptr;
+    sn.IH = d->H;
+    sn.IW = d->W;
+    sn.CinP = r8(d->Cin);
+    sn.OH = OH;
+    sn.OW = OW;
+    sn.CoutP = r8(d->Cout);
+    sn.NB = r8(d->Cout);
+    sn.cout = d->Cout;
+    sn.KH = d->KH;
+    sn.KW = d->KW;
+    sn.pad = d->pad;
+    sn.act = e->act;
+    sn.slope = e->slope;
+    if (dsr_launch_conv_smalln(sn, d->N, d->dtype, s)) return dsr_launch_status("dsr_conv_fwd(small-n)");
   }
   a.ntaps = d->KH * d->KW;
   for (int kh = 0; kh < d->KH; ++kh)
@@ -280,12 +307,37 @@ static void wgrad_plan(const dsr_conv_desc* d, WgradArgs& a) {
   a.fd_ow = fd_make((unsigned)OW);
 }
 
+static int tile_plan(const dsr_conv_desc* d, WgradTileArgs& t, bool* taps_kernel = nullptr) {
+  int OH, OW;
+  dsr_conv_out_size(d, &OH, &OW);
+  memset(&t, 0, sizeof(t));
+  int ych = dsr_wgrad_tile_plan(d->KH, d->KW, d->stride, d->N, OH, OW, r8(d->Cin), r8(d->Cout), &t);
+  if (taps_kernel) *taps_kernel = false;
+  if (ych == 0 && d->pad_mode == DSR_PAD_ZERO) {
+    ych = dsr_wgrad_taps_plan(d->KH, d->KW, d->stride, d->N, OH, OW, r8(d->Cin), r8(d->Cout), &t);
+    if (taps_kernel) *taps_kernel = ych > 0;
+  }
+  t.N = d->N;
+  t.OH = OH;
+  t.OW = OW;
+  t.IH = d->H;
+  t.IW = d->W;
+  t.CinP = r8(d->Cin);
+  t.CoutP = r8(d->Cout);
+  t.pad = d->pad;
+  t.pad_mode = d->pad_mode;
+  return ych;
+}
+
 extern "C" size_t dsr_conv_wgrad_workspace(const dsr_conv_desc* d) {
   if (check_desc(d)) return 0;
+  WgradTileArgs t;
+  int ych = tile_plan(d, t);
+  if (ych > 0) return (size_t)(ych + DSR_WGRAD_SCRATCH_SLABS) * d->KH * d->KW * t.CoutP * t.CinP * sizeof(float);
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   wgrad_plan(d, a);
-  return (size_t)a.splits * d->KH * d->KW * a.CoutP * a.CinP * sizeof(float);
+  return (size_t)(a.splits + DSR_WGRAD_SCRATCH_SLABS) * d->KH * d->KW * a.CoutP * a.CinP * sizeof(float);
 }
 
 extern "C" int dsr_conv_wgrad(const dsr_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace,
@@ -293,11 +345,25 @@ extern "C" int dsr_conv_wgrad(const dsr_conv_desc* d, const void* x, const void*
   int rc = check_desc(d);
   if (rc) return rc;
   if (!x || !dy || !dw) return dsr_fail(DSR_E_ARG, "conv_wgrad: null pointer");
+  size_t need = dsr_conv_wgrad_workspace(d);
+  if (!workspace || ws_bytes < need) return dsr_fail(DSR_E_WORKSPACE, "conv_wgrad: workspace %zu < %zu", ws_bytes, need);
+  WgradTileArgs t;
+  bool taps_kernel = false;
+  int ych = tile_plan(d, t, &taps_kernel);
+  if (ych > 0) {   // 3x3 (stride 1|2), 1x1, and 9x9 with few channels: taps derived from one staged halo tile
+    t.x = x;
+    t.dy = dy;
+    t.partial = (float*)workspace;
+    if (taps_kernel)
+      dsr_launch_wgrad_taps(t, d->KH, ych, d->dtype, s);
+    else
+      dsr_launch_wgrad_tile(t, d->KH, d->stride, ych, d->dtype, s);
+    dsr_launch_wgrad_reduce(t.partial, dw, ych, d->KH * d->KW, d->Cout, d->Cin, t.CoutP, t.CinP, s);
+    return dsr_launch_status("dsr_conv_wgrad");
+  }
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   wgrad_plan(d, a);
-  size_t need = dsr_conv_wgrad_workspace(d);
-  if (!workspace || ws_bytes < need) return dsr_fail(DSR_E_WORKSPACE, "conv_wgrad: workspace %zu < %zu", ws_bytes, need);
   a.x = x;
   a.dy = dy;
   a.partial = (float*)workspace;

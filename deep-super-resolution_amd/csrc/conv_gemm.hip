@@ -71,7 +71,41 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
   __syncthreads();   // sTaps visible
 
   U4 ra[RA], rbv[RB];
+  // fast path: zero padding and Cin a multiple of 64 -> the 8 units of a K-step share one tap (wave-uniform
+  // decode) and a row's address is (precomputed row base) + (per-step tap offset): ~8 VALU ops per vector.
+  const bool fast = a.pad_mode == DSR_PAD_ZERO && (a.CU & 7) == 0;
+  int a_base[RA], b_base[RB];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) a_base[i] = (a_nb[i] + a_iy0[i] * a.IW + a_ix0[i]) * a.CinP;
+#pragma unroll
+  for (int i = 0; i < RB; ++i) b_base[i] = (n0 + rb + 32 * i) * a.CinP;
+  const int cu8 = a.CU >> 3;
+
   auto load_step = [&](int s) {
+    if (fast) {
+      const int t = fd_div(a.fd_cu8, s);             // uniform
+      const int c8 = (s - t * cu8) * 8 + j;
+      const bool uok = t < a.ntaps;
+      const int tp = sTaps[uok ? t : 0];
+      const int dy = (int)(signed char)(tp & 0xff);
+      const int dx = (int)(signed char)((tp >> 8) & 0xff);
+      const int widx = (tp >> 16) & 0xffff;
+      const int toff = (dy * a.IW + dx) * a.CinP + c8 * 8;
+      const int woff = widx * a.NB * a.CinP + c8 * 8;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const bool inb = a_ok[i] && uok && (unsigned)(a_iy0[i] + dy) < (unsigned)a.IH &&
+                         (unsigned)(a_ix0[i] + dx) < (unsigned)a.IW;
+        ra[i] = load16_or_zero(X, (size_t)(a_base[i] + toff), inb);
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int row = rb + 32 * i;
+        const bool ok = uok && row < BN && (n0 + row) < a.NB;
+        rbv[i] = load16_or_zero(W, (size_t)(b_base[i] + woff), ok);
+      }
+      return;
+    }
     int u = s * 8 + j;
     bool uok = u < a.U;
     int uu = uok ? u : 0;
@@ -178,37 +212,49 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     return;
   }
 
+  // the activation is selected ONCE (wave-uniform) and the 16-element-per-tile loop is instantiated per choice,
+  // so the hot loop carries no per-element branches
+  auto epilogue = [&](auto actf) {
 #pragma unroll
-  for (int k = 0; k < TN; ++k) {
-    const int ct = wn * WN + 16 * k + r16;   // column inside the block tile
-    const int col = n0 + ct;
-    const bool colok = col < a.cout;
-    const float bv = ((a.flags & DSR_F_BIAS) && colok) ? a.bias[col] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < TN; ++k) {
+      const int ct = wn * WN + 16 * k + r16;   // column inside the block tile
+      const int col = n0 + ct;
+      const bool colok = col < a.cout;
+      const float bv = ((a.flags & DSR_F_BIAS) && colok) ? a.bias[col] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wm * WM + 16 * i + 4 * g + r;
-        const float v = acc[i][k][r] + bv;
-        const float vm = (m0 + row < a.M && colok) ? v : 0.f;   // statistics ignore tail rows / pad columns
-        s1 += vm;
-        s2 += vm * vm;
-        const float o = colok ? act_apply(a.act, v, slope) : 0.f;
-        *reinterpret_cast<unsigned short*>(sC + row * C_STRIDE + ct * 2) = f2h<DT>(o);
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * WM + 16 * i + 4 * g + r;
+          const float v = acc[i][k][r] + bv;
+          const float vm = (m0 + row < a.M && colok) ? v : 0.f;   // statistics ignore tail rows / pad columns
+          s1 += vm;
+          s2 += vm * vm;
+          const float o = colok ? actf(v) : 0.f;
+          *reinterpret_cast<unsigned short*>(sC + row * C_STRIDE + ct * 2) = f2h<DT>(o);
+        }
+      }
+      if (do_stats) {
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (g == 0) {
+          sStat[(wm * 2 + 0) * BN + ct] = s1;
+          sStat[(wm * 2 + 1) * BN + ct] = s2;
+        }
       }
     }
-    if (do_stats) {
-      s1 += __shfl_xor(s1, 16, 64);
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (g == 0) {
-        sStat[(wm * 2 + 0) * BN + ct] = s1;
-        sStat[(wm * 2 + 1) * BN + ct] = s2;
-      }
-    }
-  }
+  };
+  if (a.act == DSR_ACT_NONE)
+    epilogue([](float v) { return v; });
+  else if (a.act == DSR_ACT_RELU)
+    epilogue([](float v) { return v > 0.f ? v : 0.f; });
+  else if (a.act == DSR_ACT_LEAKY || a.act == DSR_ACT_PRELU)
+    epilogue([slope](float v) { return v >= 0.f ? v : v * slope; });
+  else
+    epilogue([&](float v) { return act_apply(a.act, v, slope); });
   __syncthreads();
 
   if (do_stats) {

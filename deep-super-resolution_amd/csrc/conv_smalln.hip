@@ -1,0 +1,314 @@
+// Convolutions with very few channels on one side, large kernels (the generator's 9x9 head and tail,
+// models/GAN/generator.py:47,62): the gather-GEMM kernel re-reads every input pixel once per tap from L2 (81x for
+// 9x9) to feed a 16-wide N tile, so these layers were L2-bound at ~2 % of MFMA peak.  Here the input HALO tile is
+// staged in LDS once per block and every tap is an address offset into it.
+//
+//  conv_smalln_kernel      forward, Cout <= 16, stride 1, zero padding: 4 rows x 32 columns of pixels per block,
+//                          one row per wave; weights [tap][16][Cin] stream from L1/L2 straight into B fragments.
+//  conv_wgrad_taps_kernel  weight gradient for KW-wide tap rows when Cout <= 16 or Cin <= 16: a block stages a
+//                          (R+KHB-1) x (31+KW) halo of X and an R x 32 tile of dY, its 4 waves split the KHB*KW taps.
+#include "dsr_common.h"
+#include "dsr_kernels.h"
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv_smalln_kernel(const SmallNArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sX[];   // [HR][HC][64 ch] swizzled 128-B pixels
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, r16 = lane & 15;
+  // HC is rounded up to a multiple of 8 so that the XOR swizzle of a fragment read depends on (kw + lane) only:
+  // all LDS addresses of the tap loop are  row_base(kh) [uniform]  +  table[kw][kk] [per lane, precomputed].
+  const int HR = 4 + a.KH - 1, HC = (32 + a.KW - 1 + 7) & ~7;
+  const int per_img = a.tiles_y * a.tiles_x;
+  const int t = xcd_remap(blockIdx.x, gridDim.x);   // neighbouring tiles (shared halo rows) on one XCD's L2
+  const int n = t / per_img;
+  const int rem = t - n * per_img;
+  const int oy0 = (rem / a.tiles_x) * 4, ox0 = (rem % a.tiles_x) * 32;
+  const unsigned short* __restrict__ X = reinterpret_cast<const unsigned short*>(a.x);
+  const unsigned short* __restrict__ W = reinterpret_cast<const unsigned short*>(a.w);
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const int c = tid & 7, pb = tid >> 3;
+  // B rows >= NB only feed output columns that are never stored: clamp instead of predicating
+  const int wrow = r16 < a.NB ? r16 : a.NB - 1;
+
+  int lds_off[9][2];
+#pragma unroll
+  for (int kw = 0; kw < 9; ++kw)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) lds_off[kw][kk] = (kw + r16) * 128 + (((4 * kk + g) ^ ((kw + r16) & 7)) << 4);
+
+  for (int c0 = 0; c0 < a.CinP; c0 += 64) {
+    __syncthreads();
+    const bool cok = (c0 + c * 8) < a.CinP;
+    {
+      // halo staging: ALL of this thread's (<= 16) loads are issued before the first LDS write -- one HBM/L2 round
+      // trip per tile; (hr, hc) advance without divisions
+      int hr = pb / HC, hc = pb - hr * HC;
+      U4 v[16];
+      int qq[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int iy = oy0 + hr - a.pad, ix = ox0 + hc - a.pad;
+        const bool ok = cok && hr < HR && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+        v[u] = load16_or_zero(X, ((size_t)(n * a.IH + iy) * a.IW + ix) * a.CinP + c0 + c * 8, ok);
+        qq[u] = hr < HR ? hr * HC + hc : -1;
+        hc += 32;
+        if (hc >= HC) {
+          hc -= HC;
+          ++hr;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (qq[u] >= 0) *reinterpret_cast<U4*>(sX + qq[u] * 128 + ((c ^ (qq[u] & 7)) << 4)) = v[u];
+    }
+    __syncthreads();
+    // weights stream L1/L2 -> VGPR one tap ROW ahead: while the <= 9 taps of row kh run (36 MFMAs per wave), the
+    // fragments of row kh+1 are in flight in the other register set (two named sets => static indexing).
+    const unsigned short* wlane = W + (size_t)wrow * a.CinP + c0 + g * 8;
+    const int tap_stride = a.NB * a.CinP;
+    // two register sets of <= 5 taps (kw 0..4 and kw 5..8): while one set runs its 16-20 MFMAs per wave, the loads of
+    // the next half-row are in flight in the other (named sets => static indexing; 80 VGPRs instead of 144).
+    U4 fbA[5][2], fbB[5][2];
+    auto load_half = [&](U4 (&fb)[5][2], int kh, int kw0) {
+      const unsigned short* wr = wlane + (size_t)(kh < a.KH ? kh : 0) * a.KW * tap_stride;   // uniform part
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int kw = kw0 + i;
+        const int kwc = kw < a.KW ? kw : 0;                // clamped taps are loaded but never used
+        fb[i][0] = *reinterpret_cast<const U4*>(wr + kwc * tap_stride);
+        fb[i][1] = *reinterpret_cast<const U4*>(wr + kwc * tap_stride + 32);
+      }
+    };
+    auto run_half = [&](const U4 (&fb)[5][2], int kh, int kw0) {
+      const unsigned char* rowp = sX + (wave + kh) * HC * 128;     // uniform
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int kw = kw0 + i;
+        if (kw < a.KW && kw < 9) {   // wave-uniform
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              U4 fa = *reinterpret_cast<const U4*>(rowp + lds_off[kw0 + i < 9 ? kw0 + i : 8][kk] + mt * 2048);
+              acc[mt] = mfma16<DT>(fa, fb[i][kk], acc[mt]);
+            }
+          }
+        }
+      }
+    };
+    load_half(fbA, 0, 0);
+    for (int kh = 0; kh < a.KH; ++kh) {
+      load_half(fbB, kh, 5);
+      run_half(fbA, kh, 0);
+      load_half(fbA, kh + 1, 0);
+      run_half(fbB, kh, 5);
+    }
+  }
+  // epilogue: lane (g, col=r16) holds rows 4g..4g+3 = 4 consecutive x positions of channel `col`
+  const int col = r16;
+  if (col >= a.cout) return;
+  const float bv = a.bias ? a.bias[col] : 0.f;
+  const float slope = a.prelu ? a.prelu[0] : a.slope;
+  const int oy = oy0 + wave;
+  if (oy >= a.OH) return;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int ox = ox0 + mt * 16 + 4 * g;
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = act_apply(a.act, acc[mt][r] + bv, slope);
+    if (a.out_f32) {
+      float* dst = a.out_f32 + (((size_t)n * a.cout + col) * a.OH + oy) * a.OW + ox;
+      if (ox + 3 < a.OW && (a.OW & 3) == 0) {
+        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (ox + r < a.OW) dst[r] = o[r];
+      }
+    } else {
+      unsigned short* Y = reinterpret_cast<unsigned short*>(a.y);
+      for (int r = 0; r < 4; ++r)
+        if (ox + r < a.OW) Y[((size_t)(n * a.OH + oy) * a.OW + ox + r) * a.CoutP + col] = f2h<DT>(o[r]);
+    }
+  }
+}
+
+// zero the pad channels [cout, CoutP) of a 16-bit NHWC output written column-wise by conv_smalln_kernel
+template <int DT>
+__global__ void zero_pad_channels_kernel(unsigned short* __restrict__ y, size_t P, int cout, int CoutP) {
+  size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  for (int c = cout; c < CoutP; ++c) y[p * CoutP + c] = 0;
+}
+
+int dsr_launch_conv_smalln(SmallNArgs& a, int N, int dtype, hipStream_t st) {
+  a.tiles_y = (a.OH + 3) / 4;
+  a.tiles_x = (a.OW + 31) / 32;
+  const int HR = 4 + a.KH - 1, HC = (32 + a.KW - 1 + 7) & ~7;
+  const size_t lds = (size_t)HR * HC * 128;
+  if (lds > 64 * 1024 || a.KW > 9 || (a.CinP & 63) != 0 || HR * HC > 16 * 32) return 0;
+  dim3 grid(N * a.tiles_y * a.tiles_x), block(256);
+  if (dtype == DSR_DTYPE_BF16) {
+    hipLaunchKernelGGL((conv_smalln_kernel<DSR_DTYPE_BF16>), grid, block, lds, st, a);
+    if (!a.out_f32 && a.cout < a.CoutP)
+      hipLaunchKernelGGL((zero_pad_channels_kernel<DSR_DTYPE_BF16>), dim3((unsigned)(((size_t)N * a.OH * a.OW + 255) / 256)),
+                         block, 0, st, (unsigned short*)a.y, (size_t)N * a.OH * a.OW, a.cout, a.CoutP);
+  } else {
+    hipLaunchKernelGGL((conv_smalln_kernel<DSR_DTYPE_F16>), grid, block, lds, st, a);
+    if (!a.out_f32 && a.cout < a.CoutP)
+      hipLaunchKernelGGL((zero_pad_channels_kernel<DSR_DTYPE_F16>), dim3((unsigned)(((size_t)N * a.OH * a.OW + 255) / 256)),
+                         block, 0, st, (unsigned short*)a.y, (size_t)N * a.OH * a.OW, a.cout, a.CoutP);
+  }
+  return 1;
+}
+
+// ------------------------------------------------------------------ weight gradient, wide tap rows, few channels
+__device__ __forceinline__ s16x4 tr_read_sn(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ U4 tr_frag_sn(const unsigned char* base, int p1, int p2, int chunk, int within) {
+  s16x4 lo = tr_read_sn(base + p1 * 128 + ((chunk ^ (p1 & 7)) << 4) + within);
+  s16x4 hi = tr_read_sn(base + p2 * 128 + ((chunk ^ (p2 & 7)) << 4) + within);
+  return __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// KW taps per row, KHB tap rows per block (blockIdx.y = tap-row group), 2 x 32 output pixels per tile, stride 1.
+// CT co-tiles x IT ci-tiles of 16 per wave; the 4 waves own taps w, w+4, w+8, ... of the block's KHB*KW taps.
+template <int DT, int KW, int KHB, int CT, int IT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(const WgradTileArgs a, int KH) {
+  constexpr int R = 2;
+  constexpr int HR = R - 1 + KHB, HC = 31 + KW;
+  constexpr int NTB = KHB * KW;
+  constexpr int NW = (NTB + 3) / 4;
+  __shared__ __attribute__((aligned(16))) unsigned char sX[HR * HC * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char sY[R * 32 * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
+  const int kh0 = blockIdx.y * KHB;
+  const unsigned short* __restrict__ X = reinterpret_cast<const unsigned short*>(a.x);
+  const unsigned short* __restrict__ DY = reinterpret_cast<const unsigned short*>(a.dy);
+
+  f32x4 acc[NW][CT][IT];
+#pragma unroll
+  for (int t = 0; t < NW; ++t)
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int j = 0; j < IT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int c = tid & 7, pbase = tid >> 3;
+  const bool yc_ok = (c * 8) < a.CoutP && c * 8 < CT * 16, xc_ok = (c * 8) < a.CinP && c * 8 < IT * 16;
+  int t_end = (blockIdx.z + 1) * a.tiles_per_block;
+  if (t_end > a.ntiles) t_end = a.ntiles;
+  const int per_img = a.tiles_y * a.tiles_x;
+
+  for (int t = blockIdx.z * a.tiles_per_block; t < t_end; ++t) {
+    const int n = t / per_img;
+    const int rem = t - n * per_img;
+    const int oy0 = (rem / a.tiles_x) * R, ox0 = (rem % a.tiles_x) * 32;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < R * 32 * 8 / 256; ++i) {
+      const int p = pbase + 32 * i;
+      const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
+      const bool ok = yc_ok && oy < a.OH && ox < a.OW;
+      U4 v = load16_or_zero(DY, ((size_t)(n * a.OH + oy) * a.OW + ox) * a.CoutP + c * 8, ok);
+      *reinterpret_cast<U4*>(sY + p * 128 + ((c ^ (p & 7)) << 4)) = v;
+    }
+    {
+      constexpr int NV = (HR * HC + 31) / 32;
+      U4 v[NV];
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int q = pbase + 32 * u;
+        const int hr = q / HC, hc = q - hr * HC;
+        const int iy = oy0 + hr + kh0 - a.pad, ix = ox0 + hc - a.pad;
+        const bool ok = xc_ok && q < HR * HC && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+        v[u] = load16_or_zero(X, ((size_t)(n * a.IH + iy) * a.IW + ix) * a.CinP + c * 8, ok);
+      }
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int q = pbase + 32 * u;
+        if (q < HR * HC) *reinterpret_cast<U4*>(sX + q * 128 + ((c ^ (q & 7)) << 4)) = v[u];
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+      U4 fa[CT];
+#pragma unroll
+      for (int i = 0; i < CT; ++i) {
+        const int ch = i * 16 + cc;
+        fa[i] = tr_frag_sn(sY, r * 32 + 4 * g + q4, r * 32 + 16 + 4 * g + q4, ch >> 3, (ch & 7) * 2);
+      }
+#pragma unroll
+      for (int ti = 0; ti < NW; ++ti) {
+        const int tt = wave + 4 * ti;          // wave-uniform
+        if (tt < NTB) {
+          const int khl = tt / KW, kw = tt - khl * KW;
+          const int qb = (r + khl) * HC + kw;
+          const int q1 = qb + 4 * g + q4, q2 = q1 + 16;
+#pragma unroll
+          for (int j = 0; j < IT; ++j) {
+            const int ch = j * 16 + cc;
+            U4 fb = tr_frag_sn(sX, q1, q2, ch >> 3, (ch & 7) * 2);
+#pragma unroll
+            for (int i = 0; i < CT; ++i) acc[ti][i][j] = mfma16<DT>(fa[i], fb, acc[ti][i][j]);
+          }
+        }
+      }
+    }
+  }
+  const int ntaps = KH * KW;
+  float* P = a.partial + (size_t)blockIdx.z * ntaps * a.CoutP * a.CinP;
+#pragma unroll
+  for (int ti = 0; ti < NW; ++ti) {
+    const int tt = wave + 4 * ti;
+    const int khl = tt / KW, kw = tt - khl * KW;
+    const int kh = kh0 + khl;
+    if (tt < NTB && kh < KH) {
+      const int tap = kh * KW + kw;
+#pragma unroll
+      for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < IT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = i * 16 + 4 * g + r, ci = j * 16 + l16;
+            if (co < a.CoutP && ci < a.CinP) P[((size_t)tap * a.CoutP + co) * a.CinP + ci] = acc[ti][i][j][r];
+          }
+    }
+  }
+}
+
+// returns the number of partial slabs, 0 if the shape is not handled (9x9, stride 1, one side <= 16 channels,
+// the other <= 64)
+int dsr_wgrad_taps_plan(int KH, int KW, int stride, int N, int OH, int OW, int CinP, int CoutP, WgradTileArgs* a) {
+  if (!(KH == 9 && KW == 9 && stride == 1)) return 0;
+  const bool small_out = CoutP <= 16 && CinP <= 64, small_in = CinP <= 16 && CoutP <= 64;
+  if (!small_out && !small_in) return 0;
+  a->tiles_y = (OH + 1) / 2;
+  a->tiles_x = (OW + 31) / 32;
+  a->ntiles = N * a->tiles_y * a->tiles_x;
+  a->tiles_co = a->tiles_ci = 1;
+  long long want = 512 / 3;                     // 3 tap-row groups per spatial chunk
+  if (want > a->ntiles) want = a->ntiles;
+  a->tiles_per_block = (int)((a->ntiles + want - 1) / want);
+  return (a->ntiles + a->tiles_per_block - 1) / a->tiles_per_block;
+}
+
+void dsr_launch_wgrad_taps(const WgradTileArgs& a, int KH, int ychunks, int dtype, hipStream_t st) {
+  dim3 grid(1, 3, ychunks), block(256);
+  const bool small_out = a.CoutP <= 16;
+  if (dtype == DSR_DTYPE_BF16) {
+    if (small_out)
+      hipLaunchKernelGGL((conv_wgrad_taps_kernel<DSR_DTYPE_BF16, 9, 3, 1, 4>), grid, block, 0, st, a, KH);
+    else
+      hipLaunchKernelGGL((conv_wgrad_taps_kernel<DSR_DTYPE_BF16, 9, 3, 4, 1>), grid, block, 0, st, a, KH);
+  } else {
+    if (small_out)
+      hipLaunchKernelGGL((conv_wgrad_taps_kernel<DSR_DTYPE_F16, 9, 3, 1, 4>), grid, block, 0, st, a, KH);
+    else
+      hipLaunchKernelGGL((conv_wgrad_taps_kernel<DSR_DTYPE_F16, 9, 3, 4, 1>), grid, block, 0, st, a, KH);
+  }
+}

@@ -148,26 +148,55 @@ void dsr_launch_wgrad(const WgradArgs& a, int dtype, hipStream_t st) {
 }
 
 // dw[co][ci][kh][kw] (fp32, PyTorch layout) = sum over splits of partial[split][tap][co][ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int splits, int ntaps,
-                                    int Cout, int Cin, int CoutP, int CinP) {
-  // threads walk the slab in its own order (ci fastest): coalesced reads of every split, one scattered write
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  int total = ntaps * CoutP * CinP;
+// grid.y slices the splits so that many loads are in flight; with more than one slice the first pass writes
+// slice sums to `scratch` ([slices][slab]) and a second launch folds those (deterministic order).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                           float* __restrict__ scratch, int splits, int per_slice,
+                                                           int ntaps, int Cout, int Cin, int CoutP, int CinP) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = ntaps * CoutP * CinP;
   if (idx >= total) return;
-  int ci = idx % CinP;
-  int co = (idx / CinP) % CoutP;
-  int tap = idx / (CinP * CoutP);
-  if (ci >= Cin || co >= Cout) return;
-  size_t slab = (size_t)total;
+  const size_t slab = (size_t)total;
+  const int z0 = blockIdx.y * per_slice;
+  int z1 = z0 + per_slice;
+  if (z1 > splits) z1 = splits;
   const float* p = partial + idx;
-  double s = 0.0;
-  for (int z = 0; z < splits; ++z) s += (double)p[z * slab];
-  dw[((size_t)co * Cin + ci) * ntaps + tap] = (float)s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int z = z0;
+  for (; z + 3 < z1; z += 4) {   // 4 independent loads in flight per thread
+    s0 += p[(size_t)z * slab];
+    s1 += p[(size_t)(z + 1) * slab];
+    s2 += p[(size_t)(z + 2) * slab];
+    s3 += p[(size_t)(z + 3) * slab];
+  }
+  for (; z < z1; ++z) s0 += p[(size_t)z * slab];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (scratch != nullptr) {
+    scratch[(size_t)blockIdx.y * slab + idx] = s;
+    return;
+  }
+  const int ci = idx % CinP;
+  const int co = (idx / CinP) % CoutP;
+  const int tap = idx / (CinP * CoutP);
+  if (ci < Cin && co < Cout) dw[((size_t)co * Cin + ci) * ntaps + tap] = s;
 }
 
+// `partial` must have room for splits + DSR_WGRAD_SCRATCH_SLABS slabs when splits > 32.
 void dsr_launch_wgrad_reduce(const float* partial, float* dw, int splits, int ntaps, int Cout, int Cin, int CoutP,
                              int CinP, hipStream_t st) {
-  int total = ntaps * CoutP * CinP;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partial, dw, splits, ntaps, Cout,
-                     Cin, CoutP, CinP);
+  const int total = ntaps * CoutP * CinP;
+  const int bx = (total + 255) / 256;
+  if (splits <= 32) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx, 1), dim3(256), 0, st, partial, dw, (float*)nullptr, splits, splits,
+                       ntaps, Cout, Cin, CoutP, CinP);
+    return;
+  }
+  const int slices = DSR_WGRAD_SCRATCH_SLABS;
+  const int per = (splits + slices - 1) / slices;
+  const int used = (splits + per - 1) / per;
+  float* scratch = const_cast<float*>(partial) + (size_t)splits * total;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx, used), dim3(256), 0, st, partial, dw, scratch, splits, per, ntaps,
+                     Cout, Cin, CoutP, CinP);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx, 1), dim3(256), 0, st, (const float*)scratch, dw, (float*)nullptr, used,
+                     used, ntaps, Cout, Cin, CoutP, CinP);
 }

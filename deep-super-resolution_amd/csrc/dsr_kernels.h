@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #define DSR_MAX_TAPS 96
+#define DSR_WGRAD_SCRATCH_SLABS 16
 
 #define DSR_F_BIAS 1
 #define DSR_F_STATS 2
@@ -50,7 +51,7 @@ struct ConvGemmArgs {
   float slope;
   int flags;
   int tiles_m, tiles_n;
-  FastDiv fd_ghw, fd_gw, fd_cu;
+  FastDiv fd_ghw, fd_gw, fd_cu, fd_cu8;
   int taps[DSR_MAX_TAPS];   // (dy & 0xff) | (dx & 0xff) << 8 | widx << 16
 };
 
@@ -66,6 +67,37 @@ struct WgradArgs {
   FastDiv fd_ohw, fd_ow;
 };
 void dsr_launch_wgrad(const WgradArgs& a, int dtype, hipStream_t st);
+
+// tile-resident weight gradient (3x3 stride 1|2 and 1x1): all taps from one staged halo tile
+struct WgradTileArgs {
+  const void* x;
+  const void* dy;
+  float* partial;   // [ychunks][ntaps][CoutP][CinP]
+  int N, OH, OW, IH, IW, CinP, CoutP;
+  int pad, pad_mode;
+  int tiles_co, tiles_ci;
+  int tiles_y, tiles_x, ntiles, tiles_per_block;
+};
+// returns the number of partial slabs (ychunks) the launch will write, 0 if the shape is not handled
+int dsr_wgrad_tile_plan(int KH, int KW, int stride, int N, int OH, int OW, int CinP, int CoutP, WgradTileArgs* a);
+void dsr_launch_wgrad_tile(const WgradTileArgs& a, int KH, int stride, int ychunks, int dtype, hipStream_t st);
+
+int dsr_wgrad_taps_plan(int KH, int KW, int stride, int N, int OH, int OW, int CinP, int CoutP, WgradTileArgs* a);
+void dsr_launch_wgrad_taps(const WgradTileArgs& a, int KH, int ychunks, int dtype, hipStream_t st);
+
+// forward conv with <= 16 output channels from an LDS-resident halo tile (conv_smalln.hip)
+struct SmallNArgs {
+  const void* x;
+  const void* w;      // [taps][NB][CinP]
+  void* y;            // NHWC 16-bit [N][OH][OW][CoutP] (or null)
+  float* out_f32;     // NCHW fp32 (or null)
+  const float* bias;
+  const float* prelu;
+  int IH, IW, CinP, OH, OW, CoutP, NB, cout, KH, KW, pad, act;
+  float slope;
+  int tiles_y, tiles_x;
+};
+int dsr_launch_conv_smalln(SmallNArgs& a, int N, int dtype, hipStream_t st);   // returns 0 if the halo does not fit
 
 void dsr_launch_wgrad_reduce(const float* partial, float* dw, int splits, int ntaps, int Cout, int Cin, int CoutP,
                              int CinP, hipStream_t st);

@@ -229,28 +229,40 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const unsigned short
 }
 
 // ------------------------------------------------------------------ BN-apply + activation (+ residual)
+// Every thread owns one 8-channel chunk and walks pixels: the per-channel affine parameters are loaded ONCE into
+// registers (a one-vector-per-thread version spends more load instructions on parameters than on payload and
+// reaches only ~0.8 TB/s).
 template <int DT>
-__global__ void bn_act_fwd_kernel(const unsigned short* __restrict__ y, const float* __restrict__ scale,
-                                  const float* __restrict__ shift, const unsigned short* __restrict__ residual,
-                                  unsigned short* __restrict__ out, size_t nvec, int Cp, int act, float slope_v,
-                                  const float* __restrict__ prelu) {
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nvec) return;
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const unsigned short* __restrict__ y,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const unsigned short* __restrict__ residual,
+                                                         unsigned short* __restrict__ out, size_t P, int Cp, int act,
+                                                         float slope_v, const float* __restrict__ prelu) {
   const int cpr = Cp / 8;
-  const int ch = (int)(idx % cpr);
+  const int rpi = 256 / cpr;
+  const int ch = threadIdx.x % cpr, rr = threadIdx.x / cpr;
+  if (rr >= rpi) return;
   const float slope = prelu ? prelu[0] : slope_v;
-  float f[8], r[8];
-  unpack8<DT>(*reinterpret_cast<const U4*>(y + idx * 8), f);
-  if (residual) unpack8<DT>(*reinterpret_cast<const U4*>(residual + idx * 8), r);
+  float sc[8], sh[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    int c = ch * 8 + k;
-    float v = scale ? f[k] * scale[c] + shift[c] : f[k];
-    v = act_apply(act, v, slope);
-    if (residual) v += r[k];
-    f[k] = v;
+    sc[k] = scale ? scale[ch * 8 + k] : 1.f;
+    sh[k] = scale ? shift[ch * 8 + k] : 0.f;
   }
-  *reinterpret_cast<U4*>(out + idx * 8) = pack8<DT>(f);
+  const size_t stride = (size_t)gridDim.x * rpi;
+  for (size_t p = (size_t)blockIdx.x * rpi + rr; p < P; p += stride) {
+    float f[8], r[8];
+    unpack8<DT>(*reinterpret_cast<const U4*>(y + p * Cp + ch * 8), f);
+    if (residual) unpack8<DT>(*reinterpret_cast<const U4*>(residual + p * Cp + ch * 8), r);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float v = act_apply(act, f[k] * sc[k] + sh[k], slope);
+      if (residual) v += r[k];
+      f[k] = v;
+    }
+    *reinterpret_cast<U4*>(out + p * Cp + ch * 8) = pack8<DT>(f);
+  }
 }
 
 // backward of out = act(scale*y + shift) [+ residual]; g = dout * act'(z).
@@ -344,38 +356,47 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int bl
   }
 }
 
-// pass 2: dy = scale * (g - c1 - xhat * c2)      (scale = gamma * rstd)
-// with bn == 0 (no BatchNorm, scale == nullptr): dy = g
+// pass 2: dy = scale * (g - c1 - xhat * c2)      (scale = gamma * rstd), folded per channel into
+//   dy = A*g + B*y + C,  A = scale, B = -scale*c2*rstd, C = scale*(c2*mean*rstd - c1);  eval mode: dy = scale*g.
 template <int DT>
-__global__ void bn_act_bwd_apply_kernel(const unsigned short* __restrict__ dout, const unsigned short* __restrict__ y,
-                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                        const float* __restrict__ c1, const float* __restrict__ c2,
-                                        unsigned short* __restrict__ dy, size_t nvec, int Cp, int act, float slope_v,
-                                        const float* __restrict__ prelu, int train) {
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nvec) return;
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
+    const unsigned short* __restrict__ dout, const unsigned short* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ c1, const float* __restrict__ c2, unsigned short* __restrict__ dy, size_t P, int Cp,
+    int act, float slope_v, const float* __restrict__ prelu, int train) {
   const int cpr = Cp / 8;
-  const int ch = (int)(idx % cpr);
+  const int rpi = 256 / cpr;
+  const int ch = threadIdx.x % cpr, rr = threadIdx.x / cpr;
+  if (rr >= rpi) return;
   const float slope = prelu ? prelu[0] : slope_v;
-  float d[8], f[8];
-  unpack8<DT>(*reinterpret_cast<const U4*>(dout + idx * 8), d);
-  unpack8<DT>(*reinterpret_cast<const U4*>(y + idx * 8), f);
+  float sc[8], sh[8], cb[8], cc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    int c = ch * 8 + k;
-    float sc = scale[c];
-    float z = f[k] * sc + shift[c];
-    float o = act_apply(act, z, slope);
-    float gg = d[k] * act_grad_from_out(act, (act == DSR_ACT_LEAKY || act == DSR_ACT_PRELU) ? z : o, slope);
+    const int c = ch * 8 + k;
+    sc[k] = scale[c];
+    sh[k] = shift[c];
     if (train) {
-      float xh = (f[k] - mean[c]) * rstd[c];
-      f[k] = sc * (gg - c1[c] - xh * c2[c]);
+      cb[k] = -sc[k] * c2[c] * rstd[c];
+      cc[k] = sc[k] * (c2[c] * mean[c] * rstd[c] - c1[c]);
     } else {
-      f[k] = sc * gg;   // eval mode: BN is a fixed affine map
+      cb[k] = 0.f;
+      cc[k] = 0.f;
     }
   }
-  *reinterpret_cast<U4*>(dy + idx * 8) = pack8<DT>(f);
+  const bool lin = act == DSR_ACT_LEAKY || act == DSR_ACT_PRELU;
+  const size_t stride = (size_t)gridDim.x * rpi;
+  for (size_t p = (size_t)blockIdx.x * rpi + rr; p < P; p += stride) {
+    float d[8], f[8];
+    unpack8<DT>(*reinterpret_cast<const U4*>(dout + p * Cp + ch * 8), d);
+    unpack8<DT>(*reinterpret_cast<const U4*>(y + p * Cp + ch * 8), f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float z = f[k] * sc[k] + sh[k];
+      const float gg = d[k] * act_grad_from_out(act, lin ? z : act_apply(act, z, slope), slope);
+      f[k] = sc[k] * gg + cb[k] * f[k] + cc[k];
+    }
+    *reinterpret_cast<U4*>(dy + p * Cp + ch * 8) = pack8<DT>(f);
+  }
 }
 
 // ------------------------------------------------------------------ activation backward for conv+act layers
@@ -572,21 +593,44 @@ __global__ void bce_const_kernel(const float* __restrict__ p, int n, float targe
 
 // ------------------------------------------------------------------ Adam (torch.optim.Adam defaults, no weight decay)
 // step counter lives on the device so the launch is graph-capturable.
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
-                            const int* __restrict__ step, float grad_scale) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int t = *step;
-  float bc1 = 1.f - powf(b1, (float)t);
-  float bc2 = 1.f - powf(b2, (float)t);
-  float gi = g[i] * grad_scale;   // 1/S un-does a static loss scale (fp16 storage); 1 otherwise
-  float mi = b1 * m[i] + (1.f - b1) * gi;
-  float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-  m[i] = mi;
-  v[i] = vi;
-  float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-  p[i] = p[i] - (lr / bc1) * (mi / denom);
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                                                   float b1, float b2, float eps, const int* __restrict__ step,
+                                                   float grad_scale) {
+  const int t = *step;
+  const float bc1 = 1.f - powf(b1, (float)t);
+  const float rbc2 = 1.f / sqrtf(1.f - powf(b2, (float)t));
+  const float step_size = lr / bc1;
+  const size_t n4 = n / 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pi = reinterpret_cast<float4*>(p)[i], gi = reinterpret_cast<const float4*>(g)[i];
+    float4 mi = reinterpret_cast<float4*>(m)[i], vi = reinterpret_cast<float4*>(v)[i];
+    float* pp = &pi.x;
+    float* gp = &gi.x;
+    float* mp = &mi.x;
+    float* vp = &vi.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = gp[k] * grad_scale;   // 1/S un-does a static loss scale (fp16 storage); 1 otherwise
+      mp[k] = b1 * mp[k] + (1.f - b1) * gk;
+      vp[k] = b2 * vp[k] + (1.f - b2) * gk * gk;
+      pp[k] -= step_size * (mp[k] / (sqrtf(vp[k]) * rbc2 + eps));
+    }
+    reinterpret_cast<float4*>(p)[i] = pi;
+    reinterpret_cast<float4*>(m)[i] = mi;
+    reinterpret_cast<float4*>(v)[i] = vi;
+  }
+  // tail (n not a multiple of 4): the first threads of block 0
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    const float gk = g[i] * grad_scale;
+    const float mk = b1 * m[i] + (1.f - b1) * gk;
+    const float vk = b2 * v[i] + (1.f - b2) * gk * gk;
+    m[i] = mk;
+    v[i] = vk;
+    p[i] -= step_size * (mk / (sqrtf(vk) * rbc2 + eps));
+  }
 }
 __global__ void incr_kernel(int* step) { *step += 1; }
 
@@ -660,10 +704,12 @@ extern "C" int dsr_pw_channel_stats(int dtype, const void* x, size_t P, int Cp, 
 }
 extern "C" int dsr_pw_bn_act_fwd(int dtype, const void* y, const float* scale, const float* shift, const void* residual, void* out,
                        size_t P, int Cp, int act, float slope, const float* prelu, hipStream_t st) {
-  size_t nvec = P * (Cp / 8);
-  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<DT>), dim3(nblk(nvec, 256)), dim3(256), 0, st,
+  const int rpi = 256 / (Cp / 8);
+  size_t want = (P + (size_t)rpi * 8 - 1) / ((size_t)rpi * 8);     // >= 8 pixels per thread amortise the parameter loads
+  unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<DT>), dim3(blocks), dim3(256), 0, st,
                                       (const unsigned short*)y, scale, shift, (const unsigned short*)residual,
-                                      (unsigned short*)out, nvec, Cp, act, slope, prelu));
+                                      (unsigned short*)out, P, Cp, act, slope, prelu));
   return dsr_launch_status("dsr_pw_bn_act_fwd");
 }
 extern "C" int dsr_pw_bn_act_bwd_reduce(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
@@ -684,10 +730,12 @@ extern "C" int dsr_pw_bn_bwd_finalize(const float* partial, int blocks, int C, i
 extern "C" int dsr_pw_bn_act_bwd_apply(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
                              const float* mean, const float* rstd, const float* c1, const float* c2, void* dy, size_t P,
                              int Cp, int act, float slope, const float* prelu, int train, hipStream_t st) {
-  size_t nvec = P * (Cp / 8);
-  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DT>), dim3(nblk(nvec, 256)), dim3(256), 0, st,
+  const int rpi = 256 / (Cp / 8);
+  size_t want = (P + (size_t)rpi * 8 - 1) / ((size_t)rpi * 8);
+  unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DT>), dim3(blocks), dim3(256), 0, st,
                                       (const unsigned short*)dout, (const unsigned short*)y, scale, shift, mean, rstd, c1,
-                                      c2, (unsigned short*)dy, nvec, Cp, act, slope, prelu, train));
+                                      c2, (unsigned short*)dy, P, Cp, act, slope, prelu, train));
   return dsr_launch_status("dsr_pw_bn_act_bwd_apply");
 }
 extern "C" int dsr_pw_act_bwd(int dtype, const void* dout, const void* out, void* dy, int N, int H, int W, int CyP, int CoP,
@@ -727,7 +775,9 @@ extern "C" int dsr_pw_bce_const(const float* p, int n, float target, float* loss
 }
 extern "C" int dsr_pw_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                  const int* step, float grad_scale, hipStream_t st) {
-  hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, step, grad_scale);
+  size_t want = (n / 4 + 255) / 256;
+  unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, step, grad_scale);
   return dsr_launch_status("dsr_pw_adam");
 }
 extern "C" int dsr_pw_incr(int* step, hipStream_t st) {

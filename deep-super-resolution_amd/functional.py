@@ -307,7 +307,8 @@ class ConvBNAct(torch.autograd.Function):
             check(_timed("fwd", desc, lambda: lib.dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y),
                                                                  _stream())))
             check(lib.dsr_pw_bn_finalize(_ptr(part), rows, cp, cout, cp, float(count), _ptr(gamma), _ptr(beta),
-                                         _ptr(running_mean), _ptr(running_var), _ptr(nbt), BN_MOMENTUM, BN_EPS, 1,
+                                         _ptr(running_mean), _ptr(running_var), _ptr(nbt), BN_MOMENTUM, BN_EPS,
+                                         int(cfg.get("bn_updates", 1)),
                                          _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
         else:
             ep = Epilogue(ACT_NONE, 0.0, None, _ptr(bias), None, 0, None)
@@ -679,7 +680,8 @@ class BNAct(torch.autograd.Function):
             part = torch.empty((blocks + _scr()) * 2 * cp, dtype=torch.float32, device=dev)
             check(lib.dsr_pw_channel_stats(_dt(x), _ptr(x), p, cp, blocks, rpb, _ptr(part), _stream()))
             check(lib.dsr_pw_bn_finalize(_ptr(part), blocks, cp, c, cp, float(p), _ptr(gamma), _ptr(beta),
-                                         _ptr(running_mean), _ptr(running_var), _ptr(nbt), BN_MOMENTUM, BN_EPS, 1,
+                                         _ptr(running_mean), _ptr(running_var), _ptr(nbt), BN_MOMENTUM, BN_EPS,
+                                         int(cfg.get("bn_updates", 1)),
                                          _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
         else:
             check(lib.dsr_pw_bn_eval_affine(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), BN_EPS, c,

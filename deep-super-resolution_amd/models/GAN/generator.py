@@ -33,12 +33,12 @@ class ResidualBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(num_features=64)
         self.compute_dtype = torch.bfloat16
 
-    def _block(self, x):
-        cfg1 = dict(stride=1, pad=1, act=F.ACT_PRELU, train=self.training)
+    def _block(self, x, bn_updates=1):
+        cfg1 = dict(stride=1, pad=1, act=F.ACT_PRELU, train=self.training, bn_updates=bn_updates)
         z = F.ConvBNAct.apply(x, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias,
                               self.bn1.running_mean, self.bn1.running_var, self.bn1.num_batches_tracked,
                               self.prelu1.weight, None, cfg1)                         # generator.py:15-18
-        cfg2 = dict(stride=1, pad=1, act=F.ACT_NONE, train=self.training)
+        cfg2 = dict(stride=1, pad=1, act=F.ACT_NONE, train=self.training, bn_updates=bn_updates)
         return F.ConvBNAct.apply(z, self.conv2.weight, self.conv2.bias, self.bn2.weight, self.bn2.bias,
                                  self.bn2.running_mean, self.bn2.running_var, self.bn2.num_batches_tracked,
                                  None, x, cfg2)                                       # :20-23 (x + z fused)
@@ -89,6 +89,10 @@ class Generator(nn.Module):
 
         self.out = nn.Tanh()
         self.compute_dtype = torch.bfloat16     # float16 is accepted too (inference, BASELINE config 5)
+        # momentum updates of the BatchNorm running statistics applied per train-mode forward.  The GAN step
+        # recipe calls the generator twice on the same batch with the same weights (train_GAN.py:46,56): the two
+        # outputs are identical, so steps.gan_step runs it once and sets this to 2.
+        self.bn_updates = 1
 
     def forward(self, x):
         xi = F.ToNHWC.apply(x, self.compute_dtype)
@@ -96,10 +100,11 @@ class Generator(nn.Module):
                              dict(stride=1, pad=4, act=F.ACT_PRELU))                           # :68-69
         z = x0
         for block in self.residual_blocks:                                                        # :70
-            z = block._block(z)
+            z = block._block(z, self.bn_updates)
         z = F.ConvBNAct.apply(z, self.conv2.weight, self.conv2.bias, self.bn1.weight, self.bn1.bias,
                               self.bn1.running_mean, self.bn1.running_var, self.bn1.num_batches_tracked,
-                              None, x0, dict(stride=1, pad=1, act=F.ACT_NONE, train=self.training))   # :71-74
+                              None, x0, dict(stride=1, pad=1, act=F.ACT_NONE, train=self.training,
+                                       bn_updates=self.bn_updates))                                   # :71-74
         for block in self.pixel_shuffle_blocks:                                                   # :76
             z = block._block(z)
         return F.ConvOutNCHW.apply(z, self.conv3.weight, self.conv3.bias,

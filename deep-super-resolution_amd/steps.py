@@ -18,18 +18,24 @@ def gen_l1_step(gen, opt, lr_patches, hr_patches):
     return loss.detach(), fake.detach()
 
 
-def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches):
+def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g=None, sync_d=None):
     """train_GAN.py:38-71.  Returns (loss_D, loss_G, fake) as device tensors (no host sync here)."""
+    # train_GAN.py:46 and :56 evaluate gen(lr_patches) twice with the same weights and batch statistics -- the
+    # two outputs are bit-identical and only the BatchNorm running statistics notice the second call.  One forward
+    # (with the autograd graph the G step needs) + a double running-stat update is exactly equivalent.
+    gen.bn_updates = 2
+    fake = gen(lr_patches)                                       # :46 and :56
+    gen.bn_updates = 1
     # --- discriminator
     real_d = disc(hr_patches)                                    # :44
-    fake = gen(lr_patches).detach()                              # :46
-    fake_d = disc(fake)                                          # :47
+    fake_d = disc(fake.detach())                                 # :47
     loss_d = F.bce_const(real_d, 1.0) + F.bce_const(fake_d, 0.0)  # :48, utils/GAN.py:101-105
     opt_d.zero_grad()                                            # :51 (gan_D.zero_grad())
     loss_d.backward()                                            # :52
+    if sync_d is not None:
+        sync_d()
     opt_d.step()                                                 # :53
     # --- generator
-    fake = gen(lr_patches)                                       # :56
     with torch.no_grad():
         # :58 detaches the generator output, so this D pass never sends a gradient anywhere that survives
         # (D's .grad from it is wiped by the next zero_grad, :51); it still updates D's BN running statistics.
@@ -37,6 +43,8 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches):
     loss_g = perceptual(fake, hr_patches, fake_d, None)          # :59
     opt_g.zero_grad()                                            # :62
     loss_g.backward()                                            # :63
+    if sync_g is not None:
+        sync_g()
     opt_g.step()                                                 # :64
     return loss_d.detach(), loss_g.detach(), fake.detach()
 
