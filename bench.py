@@ -72,7 +72,7 @@ def build_step(workload, dev, world):
     hr = (torch.rand(n, 3, s * f, s * f, generator=g) * 2 - 1).to(dev)   # HR ~ U(-1,1)
     D = P("dist")
     opt_g = optim.FusedAdam(gen.parameters(), lr=1e-4)
-    sync_g = D.GradSync(gen.parameters())
+    sync_g = D.GradSync(gen.parameters()).attach()
     if workload == "gen_l1_x4":
         D.broadcast_module(gen)
         F = P("functional")
@@ -93,7 +93,7 @@ def build_step(workload, dev, world):
     D.broadcast_module(gen)
     D.broadcast_module(disc)
     opt_d = optim.FusedAdam(disc.parameters(), lr=1e-4)
-    sync_d = D.GradSync(disc.parameters())
+    sync_d = D.GradSync(disc.parameters()).attach()
 
     def step():
         return steps.gan_step(gen, disc, perc, opt_g, opt_d, lr, hr, sync_g, sync_d)[1]

@@ -40,7 +40,11 @@ static int check_desc(const dsr_conv_desc* d) {
   if (d->KH > 127 || d->KW > 127) return dsr_fail(DSR_E_UNSUPPORTED, "conv: kernel too large");
   int OH = (d->H + 2 * d->pad - d->KH) / d->stride + 1, OW = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
   if (OH < 1 || OW < 1) return dsr_fail(DSR_E_ARG, "conv: output would be empty");
-  if ((long long)d->N * d->H * d->W >= (1ll << 31) / 64 * 8) return dsr_fail(DSR_E_UNSUPPORTED, "conv: tensor too large");
+  {
+    // operands are addressed with 32-bit byte offsets (buffer loads): every tensor must stay below 2 GiB
+    const long long in_b = (long long)d->N * d->H * d->W * r8(d->Cin) * 2, out_b = (long long)d->N * OH * OW * r8(d->Cout) * 2;
+    if (in_b >= (1ll << 31) || out_b >= (1ll << 31)) return dsr_fail(DSR_E_UNSUPPORTED, "conv: tensor of 2 GiB or more");
+  }
   return DSR_OK;
 }
 
@@ -75,7 +79,9 @@ extern "C" int dsr_conv_pack_weight(const dsr_conv_desc* d, const float* w, void
 
 static inline int pack_tap(int dy, int dx, int widx) { return (dy & 0xff) | ((dx & 0xff) << 8) | (widx << 16); }
 
-static void finish_args(ConvGemmArgs& a) {
+static void finish_args(ConvGemmArgs& a, int N, int wslices) {
+  a.x_bytes = (unsigned)((size_t)N * a.IH * a.IW * a.CinP * 2);
+  a.w_bytes = (unsigned)((size_t)wslices * a.NB * a.CinP * 2);
   a.CU = a.CinP / 8;
   a.U = a.ntaps * a.CU;
   a.ksteps = (a.U + 7) / 8;
@@ -160,7 +166,7 @@ extern "C" int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w
   a.ntaps = d->KH * d->KW;
   for (int kh = 0; kh < d->KH; ++kh)
     for (int kw = 0; kw < d->KW; ++kw) a.taps[kh * d->KW + kw] = pack_tap(kh - d->pad, kw - d->pad, kh * d->KW + kw);
-  finish_args(a);
+  finish_args(a, d->N, d->KH * d->KW);
   dsr_launch_conv_gemm(a, d->dtype, s);
   return dsr_launch_status("dsr_conv_fwd");
 }
@@ -261,7 +267,7 @@ extern "C" int dsr_conv_dgrad(const dsr_conv_desc* d, const void* dy, const void
         }
       }
       a.ntaps = nt;
-      finish_args(a);
+      finish_args(a, d->N, d->KH * d->KW);
       dsr_launch_conv_gemm(a, d->dtype, s);
     }
   if (folded) {

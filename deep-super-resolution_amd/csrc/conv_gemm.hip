@@ -48,9 +48,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
 
   for (int i = tid; i < a.ntaps; i += 256) sTaps[i] = a.taps[i];
 
-  const unsigned short* __restrict__ X = reinterpret_cast<const unsigned short*>(a.x);
-  const unsigned short* __restrict__ W = reinterpret_cast<const unsigned short*>(a.w);
-
   // ---- loader role: unit j of the K-step, rows rb + 32*i
   const int j = tid & 7, rb = tid >> 3;
   int a_iy0[RA], a_ix0[RA], a_nb[RA];
@@ -71,39 +68,48 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
   __syncthreads();   // sTaps visible
 
   U4 ra[RA], rbv[RB];
+  // All operand loads are raw buffer loads: a 32-bit byte offset per lane, and the hardware range check returns
+  // zeros for the offset OOB -- so "outside the image / padding / K tail / M tail" costs one v_cndmask on the
+  // offset instead of a 64-bit address select plus four selects on the data.
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
   // fast path: zero padding and Cin a multiple of 64 -> the 8 units of a K-step share one tap (wave-uniform
-  // decode) and a row's address is (precomputed row base) + (per-step tap offset): ~8 VALU ops per vector.
+  // decode) and a row's offset is (precomputed row base) + (per-step tap offset).
   const bool fast = a.pad_mode == DSR_PAD_ZERO && (a.CU & 7) == 0;
   int a_base[RA], b_base[RB];
 #pragma unroll
-  for (int i = 0; i < RA; ++i) a_base[i] = (a_nb[i] + a_iy0[i] * a.IW + a_ix0[i]) * a.CinP;
+  for (int i = 0; i < RA; ++i) a_base[i] = ((a_nb[i] + a_iy0[i] * a.IW + a_ix0[i]) * a.CinP + j * 8) * 2;   // bytes
 #pragma unroll
-  for (int i = 0; i < RB; ++i) b_base[i] = (n0 + rb + 32 * i) * a.CinP;
+  for (int i = 0; i < RB; ++i) {
+    // weight rows beyond NB only feed output columns that are never stored: clamp the row instead of predicating
+    const int row = rb + 32 * i;
+    const int co = (n0 + row) < a.NB ? (n0 + row) : a.NB - 1;
+    b_base[i] = (co * a.CinP + j * 8) * 2;
+  }
   const int cu8 = a.CU >> 3;
 
   auto load_step = [&](int s) {
     if (fast) {
-      const int t = fd_div(a.fd_cu8, s);             // uniform
-      const int c8 = (s - t * cu8) * 8 + j;
-      const bool uok = t < a.ntaps;
-      const int tp = sTaps[uok ? t : 0];
+      const int t = fd_div(a.fd_cu8, s);             // uniform; the K loop never runs past the last tap here
+      const int cbase = (s - t * cu8) * 64;          // first channel of this step
+      const int tp = sTaps[t];
       const int dy = (int)(signed char)(tp & 0xff);
       const int dx = (int)(signed char)((tp >> 8) & 0xff);
       const int widx = (tp >> 16) & 0xffff;
-      const int toff = (dy * a.IW + dx) * a.CinP + c8 * 8;
-      const int woff = widx * a.NB * a.CinP + c8 * 8;
+      const int toff = ((dy * a.IW + dx) * a.CinP + cbase) * 2;
+      const int woff = (widx * a.NB * a.CinP + cbase) * 2;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
-        const bool inb = a_ok[i] && uok && (unsigned)(a_iy0[i] + dy) < (unsigned)a.IH &&
+        const bool inb = a_ok[i] && (unsigned)(a_iy0[i] + dy) < (unsigned)a.IH &&
                          (unsigned)(a_ix0[i] + dx) < (unsigned)a.IW;
-        ra[i] = load16_or_zero(X, (size_t)(a_base[i] + toff), inb);
+        ra[i] = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(
+                                           xrsrc, inb ? (unsigned)(a_base[i] + toff) : OOB, 0, 0));
       }
 #pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const int row = rb + 32 * i;
-        const bool ok = uok && row < BN && (n0 + row) < a.NB;
-        rbv[i] = load16_or_zero(W, (size_t)(b_base[i] + woff), ok);
-      }
+      for (int i = 0; i < RB; ++i)
+        if (rb + 32 * i < BN)
+          rbv[i] = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(b_base[i] + woff), 0, 0));
       return;
     }
     int u = s * 8 + j;
@@ -120,29 +126,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
       bool inb = a_ok[i] && uok;
       int iy = pad_index(a_iy0[i] + dy, a.IH, a.pad_mode, inb);
       int ix = pad_index(a_ix0[i] + dx, a.IW, a.pad_mode, inb);
-      size_t off = ((size_t)(a_nb[i] + iy * a.IW + ix) * a.CinP + (size_t)c8 * 8);
-      ra[i] = load16_or_zero(X, off, inb);
+      unsigned off = (unsigned)(((a_nb[i] + iy * a.IW + ix) * a.CinP + c8 * 8) * 2);
+      ra[i] = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, inb ? off : OOB, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       int row = rb + 32 * i;
-      int co = n0 + row;
-      bool ok = uok && row < BN && co < a.NB;
-      size_t off = ((size_t)(widx * a.NB + co) * a.CinP + (size_t)c8 * 8);
-      rbv[i] = load16_or_zero(W, off, ok);
+      int co = (n0 + row) < a.NB ? (n0 + row) : a.NB - 1;
+      unsigned off = (unsigned)(((widx * a.NB + co) * a.CinP + c8 * 8) * 2);
+      if (row < BN) rbv[i] = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, uok ? off : OOB, 0, 0));
     }
   };
+  int st_off[RA > RB ? RA : RB];
+#pragma unroll
+  for (int i = 0; i < (RA > RB ? RA : RB); ++i) {
+    const int row = rb + 32 * i;
+    st_off[i] = row * 128 + ((j ^ (row & 7)) << 4);
+  }
   auto store_step = [&](int stage) {
 #pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      int row = rb + 32 * i;
-      *reinterpret_cast<U4*>(sA + stage * A_STAGE + row * 128 + ((j ^ (row & 7)) << 4)) = ra[i];
-    }
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<U4*>(sA + stage * A_STAGE + st_off[i]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      int row = rb + 32 * i;
-      if (row < BN) *reinterpret_cast<U4*>(sB + stage * B_STAGE + row * 128 + ((j ^ (row & 7)) << 4)) = rbv[i];
-    }
+    for (int i = 0; i < RB; ++i)
+      if (rb + 32 * i < BN) *reinterpret_cast<U4*>(sB + stage * B_STAGE + st_off[i]) = rbv[i];
   };
 
   f32x4 acc[TM][TN];

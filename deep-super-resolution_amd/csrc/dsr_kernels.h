@@ -39,6 +39,7 @@ struct ConvGemmArgs {
   const float* bias;   // [cout]
   const float* prelu;  // 1 float
   float* stats;        // [tiles_m][2][stats_stride]
+  unsigned x_bytes, w_bytes;   // buffer sizes for the hardware range check of the operand loads
   int M, GH, GW;
   int IH, IW, CinP;
   int OH, OW, CoutP;

@@ -28,20 +28,47 @@ def broadcast_module(module, src=0):
 
 
 class GradSync:
+    """Average .grad of `params` over the ranks.
+
+    attach()  registers a post-accumulate hook on every tensor of at least ``big_bytes``: its all-reduce is issued
+              the moment autograd has finished that gradient, i.e. while the rest of the backward pass is still
+              running (the discriminator's dense1.weight gradient -- 99 % of D's gradient bytes -- is the FIRST one
+              backward produces, so its ~2 GB exchange hides behind the whole conv backward).
+    launch()  (after backward) packs the remaining small gradients into flat buckets and starts their all-reduces.
+    wait()    blocks the compute stream until everything has landed and divides by the world size.
+    """
+
     def __init__(self, params, bucket_bytes=64 << 20, big_bytes=32 << 20):
         self.params = [p for p in params if p.requires_grad]
         self.bucket_bytes, self.big_bytes = bucket_bytes, big_bytes
         self._pending = []
+        self._early = set()
+        self._hooks = []
+
+    def attach(self):
+        if not is_dist() or self._hooks:
+            return self
+        for p in self.params:
+            if p.numel() * p.element_size() >= self.big_bytes:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+        return self
+
+    def _on_grad_ready(self, p):
+        if not is_dist() or p.grad is None:
+            return
+        work = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True)
+        self._pending.append(("big", work, p.grad, None, dist.get_world_size()))
+        self._early.add(id(p))
 
     def launch(self):
-        """Start averaging every .grad (call right after backward)."""
+        """Start averaging every .grad that has not been started by a hook (call right after backward)."""
         if not is_dist():
             return
         world = dist.get_world_size()
         small, size = [], 0
         for p in reversed(self.params):          # reverse registration order ~ order grads became ready
             g = p.grad
-            if g is None:
+            if g is None or id(p) in self._early:
                 continue
             nbytes = g.numel() * g.element_size()
             if nbytes >= self.big_bytes:
@@ -64,16 +91,15 @@ class GradSync:
         """Block the current stream until the averages have landed in the .grad tensors."""
         for kind, work, buf, grads, world in self._pending:
             work.wait()
-            if kind == "big":
-                buf.div_(world)
-            else:
-                buf.div_(world)
+            buf.div_(world)
+            if kind == "bucket":
                 off = 0
                 for g in grads:
                     n = g.numel()
                     g.copy_(buf[off:off + n].view_as(g))
                     off += n
         self._pending = []
+        self._early = set()
 
     def __call__(self):
         self.launch()

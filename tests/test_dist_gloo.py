@@ -30,6 +30,16 @@ def _worker(rank, world, port, q):
     sync = D.GradSync(params, bucket_bytes=100_000, big_bytes=1_000_000)     # (1024,300) fp32 = 1.2 MB -> "big" path
     sync()
     ok = all(torch.allclose(p.grad, r, rtol=1e-6, atol=1e-6) for p, r in zip(params, ref))
+    # hook path: the big tensor's all-reduce starts from autograd's post-accumulate hook, during backward
+    sync2 = D.GradSync(params, bucket_bytes=100_000, big_bytes=1_000_000).attach()
+    for p in params:
+        p.grad = None
+    loss = sum(((rank + 1.0) * (i + 1) * p).sum() for i, p in enumerate(params))
+    loss.backward()
+    early = len(sync2._pending)
+    sync2()
+    ok = ok and early == 1 and all(torch.allclose(p.grad, torch.full(p.shape, (1 + world) / 2.0 * (i + 1)))
+                                   for i, p in enumerate(params))
     # broadcast_module: rank 1 starts from garbage and must end with rank 0's values
     lin = torch.nn.Linear(4, 3)
     if rank == 1:
