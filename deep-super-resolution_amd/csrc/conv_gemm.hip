@@ -18,7 +18,7 @@
 #include "dsr_common.h"
 #include "dsr_kernels.h"
 
-template <int DT, int BM, int BN, int WGM, int WGN>
+template <int DT, int BM, int BN, int WGM, int WGN, bool FAST>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -61,13 +61,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     int rem = mm - n * (a.GH * a.GW);
     int gy = fd_div(a.fd_gw, rem);
     int gx = rem - gy * a.GW;
-    a_iy0[i] = gy * a.isy;
+    a_iy0[i] = a_ok[i] ? gy * a.isy : -(1 << 20);   // rows past M: every tap lands out of range
     a_ix0[i] = gx * a.isx;
     a_nb[i] = n * a.IH * a.IW;
   }
   __syncthreads();   // sTaps visible
 
-  U4 ra[RA], rbv[RB];
+  U4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];   // two register sets: operand tiles 2 K-steps ahead of the MFMAs
   // All operand loads are raw buffer loads: a 32-bit byte offset per lane, and the hardware range check returns
   // zeros for the offset OOB -- so "outside the image / padding / K tail / M tail" costs one v_cndmask on the
   // offset instead of a 64-bit address select plus four selects on the data.
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
   constexpr unsigned OOB = 0xFFFFFFF0u;
   // fast path: zero padding and Cin a multiple of 64 -> the 8 units of a K-step share one tap (wave-uniform
   // decode) and a row's offset is (precomputed row base) + (per-step tap offset).
-  const bool fast = a.pad_mode == DSR_PAD_ZERO && (a.CU & 7) == 0;
+  // (FAST is a template parameter: the generic path's per-row state would otherwise cost ~20 VGPRs here)
   int a_base[RA], b_base[RB];
 #pragma unroll
   for (int i = 0; i < RA; ++i) a_base[i] = ((a_nb[i] + a_iy0[i] * a.IW + a_ix0[i]) * a.CinP + j * 8) * 2;   // bytes
@@ -87,10 +87,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     const int co = (n0 + row) < a.NB ? (n0 + row) : a.NB - 1;
     b_base[i] = (co * a.CinP + j * 8) * 2;
   }
+
   const int cu8 = a.CU >> 3;
 
-  auto load_step = [&](int s) {
-    if (fast) {
+  auto load_step = [&](int s, U4 (&ra)[RA], U4 (&rbv)[RB]) {
+    if constexpr (FAST) {
       const int t = fd_div(a.fd_cu8, s);             // uniform; the K loop never runs past the last tap here
       const int cbase = (s - t * cu8) * 64;          // first channel of this step
       const int tp = sTaps[t];
@@ -101,8 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
       const int woff = (widx * a.NB * a.CinP + cbase) * 2;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
-        const bool inb = a_ok[i] && (unsigned)(a_iy0[i] + dy) < (unsigned)a.IH &&
-                         (unsigned)(a_ix0[i] + dx) < (unsigned)a.IW;
+        const bool inb = (unsigned)(a_iy0[i] + dy) < (unsigned)a.IH && (unsigned)(a_ix0[i] + dx) < (unsigned)a.IW;
         ra[i] = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(
                                            xrsrc, inb ? (unsigned)(a_base[i] + toff) : OOB, 0, 0));
       }
@@ -110,8 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
       for (int i = 0; i < RB; ++i)
         if (rb + 32 * i < BN)
           rbv[i] = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(b_base[i] + woff), 0, 0));
-      return;
-    }
+    } else {
     int u = s * 8 + j;
     bool uok = u < a.U;
     int uu = uok ? u : 0;
@@ -136,6 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
       unsigned off = (unsigned)(((widx * a.NB + co) * a.CinP + c8 * 8) * 2);
       if (row < BN) rbv[i] = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, uok ? off : OOB, 0, 0));
     }
+    }
   };
   int st_off[RA > RB ? RA : RB];
 #pragma unroll
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     const int row = rb + 32 * i;
     st_off[i] = row * 128 + ((j ^ (row & 7)) << 4);
   }
-  auto store_step = [&](int stage) {
+  auto store_step = [&](int stage, const U4 (&ra)[RA], const U4 (&rbv)[RB]) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) *reinterpret_cast<U4*>(sA + stage * A_STAGE + st_off[i]) = ra[i];
 #pragma unroll
@@ -157,19 +157,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
 #pragma unroll
     for (int k = 0; k < TN; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_step(0);
-  store_step(0);
+  // Software pipeline, depth 2 in registers + 2 LDS stages: at K-step s the tile of step s sits in LDS[s&1], the
+  // tile of s+1 is in one register set (loaded two iterations ago) and the loads of s+2 are in flight in the
+  // other.  An iteration = {write set(s+1) -> LDS[(s+1)&1]; issue loads of s+3 into that set; 32 MFMAs on
+  // LDS[s&1]; barrier}: every global load gets two full iterations of MFMA work to land.
+  const int ks = a.ksteps;
+  load_step(0, ra0, rb0);
+  store_step(0, ra0, rb0);
+  if constexpr (BN <= 128) {
+    if (ks > 1) load_step(1, ra1, rb1);
+    if (ks > 2) load_step(2, ra0, rb0);
+  }
   __syncthreads();
 
   const int sw = r16 & 7;
-  for (int s = 0; s < a.ksteps; ++s) {
-    const int cur = s & 1;
-    const bool more = (s + 1) < a.ksteps;
-    if (more) load_step(s + 1);
+  auto compute = [&](int cur) {
     const unsigned char* pa = sA + cur * A_STAGE + (wm * WM + r16) * 128;
     const unsigned char* pb = sB + cur * B_STAGE + (wn * WN + r16) * 128;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll 1
+    for (int kk = 0; kk < 2; ++kk) {   // not unrolled: keeps one set of 8 fragments live instead of two
       const int slot = ((4 * kk + g) ^ sw) << 4;
       U4 fa[TM], fb[TN];
 #pragma unroll
@@ -181,8 +187,32 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
 #pragma unroll
         for (int k = 0; k < TN; ++k) acc[i][k] = mfma16<DT>(fa[i], fb[k], acc[i][k]);
     }
-    if (more) store_step(cur ^ 1);
-    __syncthreads();
+  };
+  if constexpr (BN <= 128) {
+    for (int s = 0; s < ks; s += 2) {
+      // even step: LDS[0] = s, set1 = s+1, set0 = s+2 (in flight)
+      if (s + 1 < ks) store_step(1, ra1, rb1);
+      if (s + 3 < ks) load_step(s + 3, ra1, rb1);
+      compute(0);
+      __syncthreads();
+      if (s + 1 >= ks) break;
+      // odd step: LDS[1] = s+1, set0 = s+2, set1 = s+3 (in flight)
+      if (s + 2 < ks) store_step(0, ra0, rb0);
+      if (s + 4 < ks) load_step(s + 4, ra0, rb0);
+      compute(1);
+      __syncthreads();
+    }
+  } else {
+    // 128x128 tile: 64 accumulator + 32 fragment registers leave room for ONE register set under the 256-VGPR
+    // budget of two resident blocks (a second set spills inside the loop and measures slower): depth-1 pipeline.
+    for (int s = 0; s < ks; ++s) {
+      const int cur = s & 1;
+      const bool more = (s + 1) < ks;
+      if (more) load_step(s + 1, ra0, rb0);
+      compute(cur);
+      if (more) store_step(cur ^ 1, ra0, rb0);
+      __syncthreads();
+    }
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -330,7 +360,11 @@ static void launch_one(const ConvGemmArgs& a, hipStream_t st) {
   b.tiles_m = (a.M + BM - 1) / BM;
   b.tiles_n = (a.NB + BN - 1) / BN;
   dim3 grid(b.tiles_m * b.tiles_n), block(256);
-  hipLaunchKernelGGL((conv_gemm_kernel<DT, BM, BN, WGM, WGN>), grid, block, 0, st, b);
+  const bool fast = a.pad_mode == DSR_PAD_ZERO && (a.CU & 7) == 0 && a.ntaps > 0;
+  if (fast)
+    hipLaunchKernelGGL((conv_gemm_kernel<DT, BM, BN, WGM, WGN, true>), grid, block, 0, st, b);
+  else
+    hipLaunchKernelGGL((conv_gemm_kernel<DT, BM, BN, WGM, WGN, false>), grid, block, 0, st, b);
 }
 
 int dsr_conv_gemm_bm(int /*NB*/) { return 128; }
