@@ -10,125 +10,143 @@
 #include "dsr_common.h"
 #include "dsr_kernels.h"
 
-template <int DT>
-__global__ __launch_bounds__(256, 2) void conv_smalln_kernel(const SmallNArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char sX[];   // [HR][HC][64 ch] swizzled 128-B pixels
+// Persistent, one block per CU.  LDS = weights (all taps, only the `NB` real rows: lanes of the 16-wide B fragment
+// beyond them re-read row 0 and feed output columns that are never stored) + one 8-row x 32-column halo tile.
+// The tap loop touches LDS only (A: 4 fragments, B: 1 fragment per 4 MFMAs); the NEXT tile's halo travels
+// HBM -> registers underneath it, so no memory wait sits between two tiles' MFMA phases.
+template <int DT, int KWT>
+__global__ __launch_bounds__(512, 2) void conv_smalln_kernel(const SmallNArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
-  // HC is rounded up to a multiple of 8 so that the XOR swizzle of a fragment read depends on (kw + lane) only:
-  // all LDS addresses of the tap loop are  row_base(kh) [uniform]  +  table[kw][kk] [per lane, precomputed].
-  const int HR = 4 + a.KH - 1, HC = (32 + a.KW - 1 + 7) & ~7;
+  constexpr int TR = 8;                                  // output rows per tile: 8 waves, one row each (two waves per
+                                                         // SIMD hide each other's LDS-read latency)
+  const int HR = TR + a.KH - 1;
+  constexpr int HC = (32 + KWT - 1 + 7) & ~7;            // multiple of 8: the read swizzle depends on (kw + lane) only
+  const int ntaps = a.KH * KWT;
+  const int WR = (a.cout + 3) & ~3;                      // weight rows kept per tap (the real output channels)
+  unsigned char* sW = smem;                              // [tap][WR rows][128 B]
+  unsigned char* sX = smem + ntaps * WR * 128;           // [HR][HC][64 ch], 16-byte chunks XOR-swizzled by pixel
   const int per_img = a.tiles_y * a.tiles_x;
-  const int t = xcd_remap(blockIdx.x, gridDim.x);   // neighbouring tiles (shared halo rows) on one XCD's L2
-  const int n = t / per_img;
-  const int rem = t - n * per_img;
-  const int oy0 = (rem / a.tiles_x) * 4, ox0 = (rem % a.tiles_x) * 32;
   const unsigned short* __restrict__ X = reinterpret_cast<const unsigned short*>(a.x);
   const unsigned short* __restrict__ W = reinterpret_cast<const unsigned short*>(a.w);
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  const int c = tid & 7, pb = tid >> 3;
-  // B rows >= NB only feed output columns that are never stored: clamp instead of predicating
-  const int wrow = r16 < a.NB ? r16 : a.NB - 1;
+  const int c = tid & 7, pb = tid >> 3;                  // pb in 0..63
 
-  int lds_off[9][2];
+  for (int i = tid; i < ntaps * WR * 8; i += 512) {      // global [tap][NB][64] 16-bit -> LDS [tap][WR][64]
+    const int ch = i & 7, row = (i >> 3) % WR, tap = (i >> 3) / WR;
+    reinterpret_cast<U4*>(sW)[i] = reinterpret_cast<const U4*>(W)[(tap * a.NB + row) * 8 + ch];
+  }
+  const int wrow = r16 < WR ? r16 : 0;
+  const int w_off = wrow * 128 + g * 16;                 // + tap * WR*128 + kk*64
+
+  int lds_off[KWT][2];
 #pragma unroll
-  for (int kw = 0; kw < 9; ++kw)
+  for (int kw = 0; kw < KWT; ++kw)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) lds_off[kw][kk] = (kw + r16) * 128 + (((4 * kk + g) ^ ((kw + r16) & 7)) << 4);
 
-  for (int c0 = 0; c0 < a.CinP; c0 += 64) {
-    __syncthreads();
-    const bool cok = (c0 + c * 8) < a.CinP;
-    {
-      // halo staging: ALL of this thread's (<= 16) loads are issued before the first LDS write -- one HBM/L2 round
-      // trip per tile; (hr, hc) advance without divisions
-      int hr = pb / HC, hc = pb - hr * HC;
-      U4 v[16];
-      int qq[16];
+  constexpr int NV = (16 * HC + 63) / 64;                // halo vectors per thread: HR(<=16) x HC pixels x 8 chunks / 512
+  // (the slot -> (row, column) walk is recomputed where needed instead of being held in 3 x NV registers: the tap
+  //  loop needs those registers to keep several LDS reads in flight ahead of the MFMAs)
+  const int hr0 = pb / HC, hc0 = pb - hr0 * HC;
+  U4 v[NV];
+  auto fetch = [&](int t) {
+    const int n = t / per_img;
+    const int rem = t - n * per_img;
+    const int oy0 = (rem / a.tiles_x) * TR - a.pad, ox0 = (rem % a.tiles_x) * 32 - a.pad;
+    int hr = hr0, hc = hc0;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int iy = oy0 + hr - a.pad, ix = ox0 + hc - a.pad;
-        const bool ok = cok && hr < HR && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-        v[u] = load16_or_zero(X, ((size_t)(n * a.IH + iy) * a.IW + ix) * a.CinP + c0 + c * 8, ok);
-        qq[u] = hr < HR ? hr * HC + hc : -1;
-        hc += 32;
-        if (hc >= HC) {
-          hc -= HC;
-          ++hr;
-        }
+    for (int u = 0; u < NV; ++u) {
+      const int iy = oy0 + hr, ix = ox0 + hc;
+      const bool ok = hr < HR && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      v[u] = load16_or_zero(X, ((size_t)(n * a.IH + iy) * a.IW + ix) * a.CinP + c * 8, ok);
+      hc += 64;
+      while (hc >= HC) {
+        hc -= HC;
+        ++hr;
       }
-#pragma unroll
-      for (int u = 0; u < 16; ++u)
-        if (qq[u] >= 0) *reinterpret_cast<U4*>(sX + qq[u] * 128 + ((c ^ (qq[u] & 7)) << 4)) = v[u];
     }
-    __syncthreads();
-    // weights stream L1/L2 -> VGPR one tap ROW ahead: while the <= 9 taps of row kh run (36 MFMAs per wave), the
-    // fragments of row kh+1 are in flight in the other register set (two named sets => static indexing).
-    const unsigned short* wlane = W + (size_t)wrow * a.CinP + c0 + g * 8;
-    const int tap_stride = a.NB * a.CinP;
-    // two register sets of <= 5 taps (kw 0..4 and kw 5..8): while one set runs its 16-20 MFMAs per wave, the loads of
-    // the next half-row are in flight in the other (named sets => static indexing; 80 VGPRs instead of 144).
-    U4 fbA[5][2], fbB[5][2];
-    auto load_half = [&](U4 (&fb)[5][2], int kh, int kw0) {
-      const unsigned short* wr = wlane + (size_t)(kh < a.KH ? kh : 0) * a.KW * tap_stride;   // uniform part
+  };
+  auto stash = [&]() {
+    int hr = hr0, hc = hc0;
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int kw = kw0 + i;
-        const int kwc = kw < a.KW ? kw : 0;                // clamped taps are loaded but never used
-        fb[i][0] = *reinterpret_cast<const U4*>(wr + kwc * tap_stride);
-        fb[i][1] = *reinterpret_cast<const U4*>(wr + kwc * tap_stride + 32);
+    for (int u = 0; u < NV; ++u) {
+      const int q = hr * HC + hc;
+      if (hr < HR) *reinterpret_cast<U4*>(sX + q * 128 + ((c ^ (q & 7)) << 4)) = v[u];
+      hc += 64;
+      while (hc >= HC) {
+        hc -= HC;
+        ++hr;
       }
-    };
-    auto run_half = [&](const U4 (&fb)[5][2], int kh, int kw0) {
-      const unsigned char* rowp = sX + (wave + kh) * HC * 128;     // uniform
+    }
+  };
+  const int col = r16;
+  const float bv = (a.bias && col < a.cout) ? a.bias[col] : 0.f;
+  const float slope = a.prelu ? a.prelu[0] : a.slope;
+
+  int t = xcd_remap(blockIdx.x, gridDim.x);          // blocks of one XCD walk neighbouring tiles (shared halo rows)
+  const int tstep = gridDim.x;
+  if (t < a.ntiles) fetch(t);
+  for (; t < a.ntiles; t += tstep) {
+    __syncthreads();                                 // previous tile's fragment reads are done (and sW is written)
+    stash();
+    __syncthreads();
+    if (t + tstep < a.ntiles) fetch(t + tstep);
+
+    f32x4 acc[2];
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int kw = kw0 + i;
-        if (kw < a.KW && kw < 9) {   // wave-uniform
+    for (int i = 0; i < 2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < a.KH; ++kh) {
+      const unsigned char* rowp = sX + (wave + kh) * HC * 128;              // uniform
+      const unsigned char* wp = sW + kh * KWT * WR * 128 + w_off;
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
+      for (int kw = 0; kw < KWT; ++kw) {
+        // all 10 fragments of this tap first, then its 8 MFMAs: the scheduler can run the next tap's reads under them
+        U4 fb[2], fa[2][2];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-              U4 fa = *reinterpret_cast<const U4*>(rowp + lds_off[kw0 + i < 9 ? kw0 + i : 8][kk] + mt * 2048);
-              acc[mt] = mfma16<DT>(fa, fb[i][kk], acc[mt]);
+        for (int kk = 0; kk < 2; ++kk) {
+          fb[kk] = *reinterpret_cast<const U4*>(wp + kw * WR * 128 + kk * 64);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            fa[kk][mt] = *reinterpret_cast<const U4*>(rowp + lds_off[kw][kk] + mt * 2048);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i] = mfma16<DT>(fa[kk][i], fb[kk], acc[i]);
+      }
+    }
+
+    // epilogue: lane (g, col=r16) holds rows 4g..4g+3 = 4 consecutive x positions of channel `col`
+    const int n = t / per_img;
+    const int rem = t - n * per_img;
+    const int oyb = (rem / a.tiles_x) * TR + wave, ox0 = (rem % a.tiles_x) * 32;
+    if (col < a.cout) {
+#pragma unroll
+      for (int rr = 0; rr < 1; ++rr) {
+        const int oy = oyb + rr;
+        if (oy >= a.OH) continue;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int ox = ox0 + mt * 16 + 4 * g;
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = act_apply(a.act, acc[mt][r] + bv, slope);
+          if (a.out_f32) {
+            float* dst = a.out_f32 + (((size_t)n * a.cout + col) * a.OH + oy) * a.OW + ox;
+            if (ox + 3 < a.OW && (a.OW & 3) == 0) {
+              *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+              for (int r = 0; r < 4; ++r)
+                if (ox + r < a.OW) dst[r] = o[r];
             }
+          } else {
+            unsigned short* Y = reinterpret_cast<unsigned short*>(a.y);
+            for (int r = 0; r < 4; ++r)
+              if (ox + r < a.OW) Y[((size_t)(n * a.OH + oy) * a.OW + ox + r) * a.CoutP + col] = f2h<DT>(o[r]);
           }
         }
       }
-    };
-    load_half(fbA, 0, 0);
-    for (int kh = 0; kh < a.KH; ++kh) {
-      load_half(fbB, kh, 5);
-      run_half(fbA, kh, 0);
-      load_half(fbA, kh + 1, 0);
-      run_half(fbB, kh, 5);
-    }
-  }
-  // epilogue: lane (g, col=r16) holds rows 4g..4g+3 = 4 consecutive x positions of channel `col`
-  const int col = r16;
-  if (col >= a.cout) return;
-  const float bv = a.bias ? a.bias[col] : 0.f;
-  const float slope = a.prelu ? a.prelu[0] : a.slope;
-  const int oy = oy0 + wave;
-  if (oy >= a.OH) return;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int ox = ox0 + mt * 16 + 4 * g;
-    float o[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = act_apply(a.act, acc[mt][r] + bv, slope);
-    if (a.out_f32) {
-      float* dst = a.out_f32 + (((size_t)n * a.cout + col) * a.OH + oy) * a.OW + ox;
-      if (ox + 3 < a.OW && (a.OW & 3) == 0) {
-        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-      } else {
-        for (int r = 0; r < 4; ++r)
-          if (ox + r < a.OW) dst[r] = o[r];
-      }
-    } else {
-      unsigned short* Y = reinterpret_cast<unsigned short*>(a.y);
-      for (int r = 0; r < 4; ++r)
-        if (ox + r < a.OW) Y[((size_t)(n * a.OH + oy) * a.OW + ox + r) * a.CoutP + col] = f2h<DT>(o[r]);
     }
   }
 }
@@ -141,23 +159,34 @@ __global__ void zero_pad_channels_kernel(unsigned short* __restrict__ y, size_t 
   for (int c = cout; c < CoutP; ++c) y[p * CoutP + c] = 0;
 }
 
+static bool g_smalln_attr_set[2] = {false, false};
+
 int dsr_launch_conv_smalln(SmallNArgs& a, int N, int dtype, hipStream_t st) {
-  a.tiles_y = (a.OH + 3) / 4;
+  a.tiles_y = (a.OH + 7) / 8;
   a.tiles_x = (a.OW + 31) / 32;
-  const int HR = 4 + a.KH - 1, HC = (32 + a.KW - 1 + 7) & ~7;
-  const size_t lds = (size_t)HR * HC * 128;
-  if (lds > 64 * 1024 || a.KW > 9 || (a.CinP & 63) != 0 || HR * HC > 16 * 32) return 0;
-  dim3 grid(N * a.tiles_y * a.tiles_x), block(256);
+  const int HR = 8 + a.KH - 1, HC = (32 + a.KW - 1 + 7) & ~7;
+  const size_t lds = (size_t)HR * HC * 128 + (size_t)a.KH * a.KW * ((a.cout + 3) & ~3) * 128;
+  if (lds > 160 * 1024 || a.KW != 9 || a.KH > 9 || a.CinP != 64) return 0;
+  a.ntiles = N * a.tiles_y * a.tiles_x;
+  dim3 grid(a.ntiles < 256 ? a.ntiles : 256), block(512);   // persistent: one 8-wave block per CU
+  const int di = dtype == DSR_DTYPE_BF16 ? 0 : 1;
+  if (!g_smalln_attr_set[di]) {   // > 64 KB of dynamic LDS needs the opt-in once per kernel (not a stream operation)
+    if (di == 0)
+      hipFuncSetAttribute((const void*)conv_smalln_kernel<DSR_DTYPE_BF16, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    else
+      hipFuncSetAttribute((const void*)conv_smalln_kernel<DSR_DTYPE_F16, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    g_smalln_attr_set[di] = true;
+  }
   if (dtype == DSR_DTYPE_BF16) {
-    hipLaunchKernelGGL((conv_smalln_kernel<DSR_DTYPE_BF16>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((conv_smalln_kernel<DSR_DTYPE_BF16, 9>), grid, block, lds, st, a);
     if (!a.out_f32 && a.cout < a.CoutP)
       hipLaunchKernelGGL((zero_pad_channels_kernel<DSR_DTYPE_BF16>), dim3((unsigned)(((size_t)N * a.OH * a.OW + 255) / 256)),
-                         block, 0, st, (unsigned short*)a.y, (size_t)N * a.OH * a.OW, a.cout, a.CoutP);
+                         dim3(256), 0, st, (unsigned short*)a.y, (size_t)N * a.OH * a.OW, a.cout, a.CoutP);
   } else {
-    hipLaunchKernelGGL((conv_smalln_kernel<DSR_DTYPE_F16>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((conv_smalln_kernel<DSR_DTYPE_F16, 9>), grid, block, lds, st, a);
     if (!a.out_f32 && a.cout < a.CoutP)
       hipLaunchKernelGGL((zero_pad_channels_kernel<DSR_DTYPE_F16>), dim3((unsigned)(((size_t)N * a.OH * a.OW + 255) / 256)),
-                         block, 0, st, (unsigned short*)a.y, (size_t)N * a.OH * a.OW, a.cout, a.CoutP);
+                         dim3(256), 0, st, (unsigned short*)a.y, (size_t)N * a.OH * a.OW, a.cout, a.CoutP);
   }
   return 1;
 }

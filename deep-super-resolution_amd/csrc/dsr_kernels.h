@@ -96,7 +96,7 @@ struct SmallNArgs {
   const float* prelu;
   int IH, IW, CinP, OH, OW, CoutP, NB, cout, KH, KW, pad, act;
   float slope;
-  int tiles_y, tiles_x;
+  int tiles_y, tiles_x, ntiles;
 };
 int dsr_launch_conv_smalln(SmallNArgs& a, int N, int dtype, hipStream_t st);   // returns 0 if the halo does not fit
 

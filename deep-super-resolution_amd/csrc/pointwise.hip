@@ -96,11 +96,13 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const float* __restri
 // returns the number of rows left (and the pointer to use); scratch = `partial + rows*width` (caller reserves
 // DSR_COMPACT_ROWS extra rows behind every partial buffer, see dsr_pw_scratch_rows()).
 static const float* compact_rows(const float* partial, int rows, int width, int* rows_out, hipStream_t st) {
-  if (rows <= 4 * DSR_COMPACT_ROWS) {
+  if (rows <= 32) {
     *rows_out = rows;
     return partial;
   }
-  int rpc = (rows + DSR_COMPACT_ROWS - 1) / DSR_COMPACT_ROWS;
+  // few rows in: the finalize kernels walk them serially with one thread per channel (a latency chain)
+  const int target = rows >= 4096 ? DSR_COMPACT_ROWS : 16;
+  int rpc = (rows + target - 1) / target;
   int nch = (rows + rpc - 1) / rpc;
   float* out = const_cast<float*>(partial) + (size_t)rows * width;
   hipLaunchKernelGGL(compact_rows_kernel, dim3((width + 63) / 64, nch), dim3(256), 0, st, partial, rows, width, rpc, out);
@@ -433,14 +435,19 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const unsigned short* __re
         int w = (int)(p % W);
         int h = (int)((p / W) % H);
         int n = (int)(p / ((size_t)W * H));
+        // conv channels 8ch..8ch+7 = shuffle channels c0, c0+1 (c0 = 2ch) at the 4 sub-pixels: one 4-byte load per
+        // sub-pixel and tensor instead of eight 2-byte gathers
+        const int c0 = ch * 2;
+        const bool cok = c0 < CoP;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          int cy = ch * 8 + k;
-          int c = cy >> 2, i = (cy >> 1) & 1, jx = cy & 1;
-          size_t q = ((size_t)(n * 2 * H + 2 * h + i) * (2 * W) + 2 * w + jx) * CoP + c;
-          bool ok = c < CoP;
-          d[k] = ok ? h2f<DT>(dout[q]) : 0.f;
-          o[k] = ok ? h2f<DT>(out[q]) : 0.f;
+        for (int sub = 0; sub < 4; ++sub) {
+          const size_t q = ((size_t)(n * 2 * H + 2 * h + (sub >> 1)) * (2 * W) + 2 * w + (sub & 1)) * CoP + c0;
+          const unsigned dv = cok ? *reinterpret_cast<const unsigned*>(dout + q) : 0u;
+          const unsigned ov = cok ? *reinterpret_cast<const unsigned*>(out + q) : 0u;
+          d[sub] = h2f<DT>((unsigned short)(dv & 0xffff));
+          d[4 + sub] = h2f<DT>((unsigned short)(dv >> 16));
+          o[sub] = h2f<DT>((unsigned short)(ov & 0xffff));
+          o[4 + sub] = h2f<DT>((unsigned short)(ov >> 16));
         }
       }
       float g[8];
@@ -596,7 +603,7 @@ __global__ void bce_const_kernel(const float* __restrict__ p, int n, float targe
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
                                                    float b1, float b2, float eps, const int* __restrict__ step,
-                                                   float grad_scale) {
+                                                   float grad_scale, unsigned short* __restrict__ shadow16) {
   const int t = *step;
   const float bc1 = 1.f - powf(b1, (float)t);
   const float rbc2 = 1.f / sqrtf(1.f - powf(b2, (float)t));
@@ -620,6 +627,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     reinterpret_cast<float4*>(p)[i] = pi;
     reinterpret_cast<float4*>(m)[i] = mi;
     reinterpret_cast<float4*>(v)[i] = vi;
+    if (shadow16) {   // bf16 image of the updated parameter (dense1's MFMA operand) without a separate cast pass
+      uint2 h;
+      h.x = (unsigned)f2h<DSR_DTYPE_BF16>(pi.x) | ((unsigned)f2h<DSR_DTYPE_BF16>(pi.y) << 16);
+      h.y = (unsigned)f2h<DSR_DTYPE_BF16>(pi.z) | ((unsigned)f2h<DSR_DTYPE_BF16>(pi.w) << 16);
+      reinterpret_cast<uint2*>(shadow16)[i] = h;
+    }
   }
   // tail (n not a multiple of 4): the first threads of block 0
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -630,6 +643,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     m[i] = mk;
     v[i] = vk;
     p[i] -= step_size * (mk / (sqrtf(vk) * rbc2 + eps));
+    if (shadow16) shadow16[i] = f2h<DSR_DTYPE_BF16>(p[i]);
   }
 }
 __global__ void incr_kernel(int* step) { *step += 1; }
@@ -774,10 +788,11 @@ extern "C" int dsr_pw_bce_const(const float* p, int n, float target, float* loss
   return dsr_launch_status("dsr_pw_bce_const");
 }
 extern "C" int dsr_pw_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-                 const int* step, float grad_scale, hipStream_t st) {
+                 const int* step, float grad_scale, void* shadow_bf16, hipStream_t st) {
   size_t want = (n / 4 + 255) / 256;
   unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, step, grad_scale);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, step, grad_scale,
+                     (unsigned short*)shadow_bf16);
   return dsr_launch_status("dsr_pw_adam");
 }
 extern "C" int dsr_pw_incr(int* step, hipStream_t st) {

@@ -481,6 +481,21 @@ def shadow16(weight, dtype):
     return out
 
 
+def shadow_for_update(weight):
+    """The bf16 shadow tensor of `weight` if one exists (so the optimiser can refresh it in its own pass)."""
+    hit = _shadow_cache.get((id(weight), torch.bfloat16, tuple(weight.shape)))
+    if hit is not None and hit[2]() is weight and weight.is_contiguous():
+        return hit[1]
+    return None
+
+
+def mark_shadow_current(weight):
+    key = (id(weight), torch.bfloat16, tuple(weight.shape))
+    hit = _shadow_cache.get(key)
+    if hit is not None:
+        _shadow_cache[key] = (_version(weight), hit[1], hit[2])
+
+
 class DenseHead(torch.autograd.Function):
     """sigmoid(Linear(1024,1)(leaky_relu(Linear(K,1024)(flatten_CHW(x)), 0.2)))  -- discriminator.py:65-72.
 

@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .functional import _ptr, _stream, bump, check
+from .functional import _ptr, _stream, bump, check, mark_shadow_current, shadow_for_update
 
 
 class FusedAdam:
@@ -38,6 +38,9 @@ class FusedAdam:
             g = p.grad
             if g.dtype != torch.float32 or not g.is_contiguous():
                 g = g.float().contiguous()
+            sh = shadow_for_update(p)        # bf16 image kept by DenseHead for this matrix (or None)
             check(lib.dsr_pw_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), self.lr, self.betas[0], self.betas[1],
-                                  self.eps, _ptr(self.step_t), self.grad_scale, st))
+                                  self.eps, _ptr(self.step_t), self.grad_scale, _ptr(sh), st))
             bump(p)
+            if sh is not None:
+                mark_shadow_current(p)

@@ -27,8 +27,7 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
     fake = gen(lr_patches)                                       # :46 and :56
     gen.bn_updates = 1
     # --- discriminator
-    real_d = disc(hr_patches)                                    # :44
-    fake_d = disc(fake.detach())                                 # :47
+    real_d, fake_d = disc.forward_pair(hr_patches, fake.detach())   # :44, :47 (BN statistics per batch, as there)
     loss_d = F.bce_const(real_d, 1.0) + F.bce_const(fake_d, 0.0)  # :48, utils/GAN.py:101-105
     opt_d.zero_grad()                                            # :51 (gan_D.zero_grad())
     loss_d.backward()                                            # :52

@@ -128,9 +128,10 @@ int dsr_pw_add(int dtype, const void* a, const void* b, void* out, size_t nvec, 
 int dsr_pw_diff_loss(const float* pred, const float* tgt, float* grad, size_t n, int mode, float* partial, int blocks,
                      dsr_stream_t s);
 int dsr_pw_bce_const(const float* p, int n, float target, float* loss, float* grad, int accumulate, dsr_stream_t s);
-/* torch.optim.Adam defaults; g is multiplied by grad_scale first (1/S when a static loss scale S is in use) */
+/* torch.optim.Adam defaults; g is multiplied by grad_scale first (1/S when a static loss scale S is in use);
+ * shadow_bf16 (nullable): also write the bf16 image of the updated parameter (same layout) */
 int dsr_pw_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-                const int* step, float grad_scale, dsr_stream_t s);
+                const int* step, float grad_scale, void* shadow_bf16, dsr_stream_t s);
 int dsr_pw_incr(int* step, dsr_stream_t s);
 
 /* ------------------------------------------------------------------ discriminator dense head (linear.hip)

@@ -52,9 +52,10 @@ def from_nhwc(y, c):
 
 
 # ----------------------------------------------------------------------------- single ops
-def test_dense_head(dev):
+@pytest.mark.parametrize("n", [5, 40])
+def test_dense_head(dev, n):
     F = P("functional")
-    n, c, h, w = 5, 512, 2, 3
+    c, h, w = 512, 2, 3
     k = c * h * w
     x = bfr(filler.tensor("dh:x", (n, c, h, w)))
     w1 = bfr(filler.tensor("dh:w1", (1024, k), float(np.sqrt(3.0 / k))))
@@ -219,6 +220,21 @@ def test_discriminator(dev, hw, n):
     for k, v in d.state_dict().items():
         if "running_" in k:
             assert rel_err(v.cpu(), osd[k]) < 2e-2, k
+    # forward_pair == two separate calls (same outputs, same BatchNorm bookkeeping)
+    d2 = Dm.Discriminator(hw)
+    d2.load_state_dict(sd)
+    d2.to(dev).train()
+    x2 = filler.tensor("in:disc2" + str(hw), (n, 3, hw[0], hw[1]))
+    with torch.no_grad():
+        pa, pb = d2.forward_pair(x.to(dev), x2.to(dev))
+        d3 = Dm.Discriminator(hw)
+        d3.load_state_dict(sd)
+        d3.to(dev).train()
+        qa, qb = d3(x.to(dev)), d3(x2.to(dev))
+    assert (pa - qa).abs().max().item() < 2e-3 and (pb - qb).abs().max().item() < 2e-3
+    for k, v in d2.state_dict().items():
+        assert torch.equal(v, d3.state_dict()[k]) or "dense" in k or v.dtype != torch.float32 or \
+            (v - d3.state_dict()[k]).abs().max().item() < 1e-6, k
 
 
 def test_vgg_loss(dev):
