@@ -56,9 +56,15 @@ extern "C" int dsr_conv_out_size(const dsr_conv_desc* d, int* OH, int* OW) {
   return DSR_OK;
 }
 
+static bool is_c64(const dsr_conv_desc* d) {
+  return d->Cin == 64 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
+         d->pad_mode == DSR_PAD_ZERO;
+}
+
 extern "C" int dsr_conv_stats_rows(const dsr_conv_desc* d) {
   int OH, OW;
   if (dsr_conv_out_size(d, &OH, &OW)) return -1;
+  if (is_c64(d)) return dsr_c64_tiles(d->N, OH, OW);      // the trunk kernel writes one statistics row per spatial tile
   long long M = (long long)d->N * OH * OW;
   return (int)((M + 127) / 128);
 }
@@ -136,6 +142,28 @@ extern "C" int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w
     a.OH = OH;
     a.OW = OW;
     a.CoutP = r8(d->Cout);
+  }
+  if (is_c64(d) && !e->pixel_shuffle && !e->out_nchw_f32) {
+    C64Args c;
+    memset(&c, 0, sizeof(c));
+    c.x = x;
+    c.w = w_fwd;
+    c.y = y;
+    c.bias = e->bias;
+    c.prelu = e->prelu;
+    c.stats = e->stats_partial;
+    c.H = d->H;
+    c.W = d->W;
+    c.act = e->act;
+    c.slope = e->slope;
+    c.flags = a.flags;
+    for (int kh = 0; kh < 3; ++kh)
+      for (int kw = 0; kw < 3; ++kw) {
+        c.tap_y[kh * 3 + kw] = kh;
+        c.tap_x[kh * 3 + kw] = kw;
+      }
+    dsr_launch_conv_c64(c, d->N, d->dtype, s);
+    return dsr_launch_status("dsr_conv_fwd(c64)");
   }
   if (d->Cout <= 16 && d->stride == 1 && d->pad_mode == DSR_PAD_ZERO && d->KH * d->KW >= 9 && !e->stats_partial &&
       !e->pixel_shuffle) {
@@ -229,6 +257,23 @@ extern "C" int dsr_conv_dgrad(const dsr_conv_desc* d, const void* dy, const void
     size_t need = dsr_conv_dgrad_workspace(d);
     if (!workspace || ws_bytes < need) return dsr_fail(DSR_E_WORKSPACE, "conv_dgrad: workspace %zu < %zu", ws_bytes, need);
     target = workspace;
+  }
+  if (is_c64(d)) {   // mirrored taps on the [tap][ci][co] weight image
+    C64Args c;
+    memset(&c, 0, sizeof(c));
+    c.x = dy;
+    c.w = w_dgrad;
+    c.y = dx;
+    c.H = d->H;
+    c.W = d->W;
+    c.act = DSR_ACT_NONE;
+    for (int kh = 0; kh < 3; ++kh)
+      for (int kw = 0; kw < 3; ++kw) {
+        c.tap_y[kh * 3 + kw] = 2 - kh;
+        c.tap_x[kh * 3 + kw] = 2 - kw;
+      }
+    dsr_launch_conv_c64(c, d->N, d->dtype, s);
+    return dsr_launch_status("dsr_conv_dgrad(c64)");
   }
   const int st = d->stride;
   for (int ph = 0; ph < st; ++ph)

@@ -1,0 +1,199 @@
+// 3x3 / stride 1 / zero-pad convolution with 64 input and 64 output channels -- the SRGAN trunk
+// (models/GAN/generator.py:7,11,52: 33 forward + 33 input-grad launches per generator pass) and every other
+// 64->64 layer (VGG conv1_2).  The generic gather kernel spends this shape's short K loop (9 steps) mostly in its
+// prologue/epilogue and re-reads weights and input per K-step; here
+//   * the block is persistent and its waves keep ALL weight fragments of their 32-channel half in registers
+//     (9 taps x 2 k-halves x 2 n-tiles = 36 fragments = 144 VGPRs) for the whole launch,
+//   * the 2-row x 32-column pixel tile's input HALO (4 x 34 pixels) is staged once in LDS and every tap is an
+//     address offset into it (A fragments: one conflict-free ds_read_b128 per 2 MFMAs),
+//   * the NEXT tile's halo travels HBM -> registers under the current tile's 72 MFMAs per wave,
+//     (2-row tiles: 144 weight + 16 accumulator + 16 fragment + 20 prefetch registers fit two waves per SIMD)
+// so the MFMA phase touches LDS only.  Same epilogue contract as conv_gemm (bias, activation, BatchNorm
+// sum / sum-of-squares rows -- one row per spatial TILE here --, 16-byte NHWC stores).  dgrad = the same kernel on the
+// [tap][ci][co] weight image with mirrored tap offsets.
+#include "dsr_common.h"
+#include "dsr_kernels.h"
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
+  constexpr int HC = 40;                       // halo row pitch in pixels (34 used; multiple of 8 keeps the swizzle row-free)
+  constexpr int TR = 2;                        // tile rows (one per wave pair)
+  constexpr int HRW = TR + 2;                  // halo rows
+  constexpr int X_BYTES = HRW * HC * 128;      // 20,480
+  constexpr int C_STRIDE = 64 * 2 + 16;
+  __shared__ __attribute__((aligned(16))) unsigned char sX[X_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char sC[TR * 32 * C_STRIDE];
+  __shared__ float sStat[2][2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, r16 = lane & 15;
+  const int wp = wave >> 1, wc = wave & 1;     // tile row, channel half (32 co)
+  const unsigned short* __restrict__ X = reinterpret_cast<const unsigned short*>(a.x);
+  const unsigned short* __restrict__ W = reinterpret_cast<const unsigned short*>(a.w);
+  unsigned short* __restrict__ Y = reinterpret_cast<unsigned short*>(a.y);
+
+  // ---- weights: registers, once (B operand: rows = output channels wc*32 + nt*16 + r16)
+  U4 fw[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        fw[t][kk][nt] = *reinterpret_cast<const U4*>(W + ((size_t)(t * 64 + wc * 32 + nt * 16 + r16)) * 64 + kk * 32 + g * 8);
+
+  // A-fragment LDS offsets: pixel column (tx + r16) -> (tx + r16)*128 + swizzled chunk; + row*HC*128 + hx*2048
+  int lds_off[3][2];
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) lds_off[tx][kk] = (tx + r16) * 128 + (((4 * kk + g) ^ ((tx + r16) & 7)) << 4);
+
+  const int c = tid & 7, pb = tid >> 3;        // loader: chunk c of halo pixels pb + 32u
+  constexpr int NV = (HRW * HC + 31) / 32;     // 5
+  const int hr0 = pb / HC, hc0 = pb - hr0 * HC;
+  const int per_img = a.tiles_y * a.tiles_x;
+  U4 v[NV];
+  auto fetch = [&](int t) {
+    const int n = t / per_img;
+    const int rem = t - n * per_img;
+    const int oy0 = (rem / a.tiles_x) * TR - 1, ox0 = (rem % a.tiles_x) * 32 - 1;
+    int hr = hr0, hc = hc0;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int iy = oy0 + hr, ix = ox0 + hc;
+      const bool ok = hr < HRW && hc < 34 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      v[u] = load16_or_zero(X, ((size_t)(n * a.H + iy) * a.W + ix) * 64 + c * 8, ok);
+      hc += 32;
+      if (hc >= HC) {
+        hc -= HC;
+        ++hr;
+      }
+    }
+  };
+  auto stash = [&]() {
+    int hr = hr0, hc = hc0;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int q = hr * HC + hc;
+      if (hr < HRW) *reinterpret_cast<U4*>(sX + q * 128 + ((c ^ (q & 7)) << 4)) = v[u];
+      hc += 32;
+      if (hc >= HC) {
+        hc -= HC;
+        ++hr;
+      }
+    }
+  };
+
+  const float slope = (a.flags & DSR_F_PRELU_PTR) ? a.prelu[0] : a.slope;
+  const bool do_stats = (a.flags & DSR_F_STATS) != 0;
+  float bias_v[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) bias_v[nt] = (a.flags & DSR_F_BIAS) ? a.bias[wc * 32 + nt * 16 + r16] : 0.f;
+
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tstep = gridDim.x;
+  if (t < a.ntiles) fetch(t);
+  for (; t < a.ntiles; t += tstep) {
+    __syncthreads();                           // previous tile: fragment reads and C-tile reads are done
+    stash();
+    __syncthreads();
+    if (t + tstep < a.ntiles) fetch(t + tstep);
+
+    f32x4 acc[2][2];                           // m-tile = half hx of the wave's row ; n-tile nt
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      const int ty = a.tap_y[tp], tx = a.tap_x[tp];   // uniform, 0..2 (halo-relative)
+      const unsigned char* rowp = sX + (wp + ty) * HC * 128;
+      const int o0 = tx == 0 ? lds_off[0][0] : (tx == 1 ? lds_off[1][0] : lds_off[2][0]);
+      const int o1 = tx == 0 ? lds_off[0][1] : (tx == 1 ? lds_off[1][1] : lds_off[2][1]);
+      U4 fa[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[0][i] = *reinterpret_cast<const U4*>(rowp + i * 2048 + o0);
+        fa[1][i] = *reinterpret_cast<const U4*>(rowp + i * 2048 + o1);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[i][nt] = mfma16<DT>(fa[kk][i], fw[tp][kk][nt], acc[i][nt]);
+    }
+
+    // ---- epilogue
+    const int n = t / per_img;
+    const int rem = t - n * per_img;
+    const int oy0 = (rem / a.tiles_x) * TR, ox0 = (rem % a.tiles_x) * 32;
+    auto epilogue = [&](auto actf) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int col = wc * 32 + nt * 16 + r16;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int oy = oy0 + wp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int px = i * 16 + 4 * g + r;
+            const float val = acc[i][nt][r] + bias_v[nt];
+            const float vm = (oy < a.H && ox0 + px < a.W) ? val : 0.f;
+            s1 += vm;
+            s2 += vm * vm;
+            const int prow = wp * 32 + px;                       // pixel index inside the tile
+            *reinterpret_cast<unsigned short*>(sC + prow * C_STRIDE + col * 2) = f2h<DT>(actf(val));
+          }
+        }
+        if (do_stats) {
+          s1 += __shfl_xor(s1, 16, 64);
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 16, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          if (g == 0) {
+            sStat[wp][0][col] = s1;
+            sStat[wp][1][col] = s2;
+          }
+        }
+      }
+    };
+    if (a.act == DSR_ACT_NONE)
+      epilogue([](float x) { return x; });
+    else if (a.act == DSR_ACT_RELU)
+      epilogue([](float x) { return x > 0.f ? x : 0.f; });
+    else if (a.act == DSR_ACT_LEAKY || a.act == DSR_ACT_PRELU)
+      epilogue([slope](float x) { return x >= 0.f ? x : x * slope; });
+    else
+      epilogue([&](float x) { return act_apply(a.act, x, slope); });
+    __syncthreads();
+    if (do_stats && tid < 128) {
+      const int which = tid >> 6, col = tid & 63;
+      a.stats[((size_t)t * 2 + which) * 64 + col] = sStat[0][which][col] + sStat[1][which][col];
+    }
+    for (int idx = tid; idx < TR * 32 * 8; idx += 256) {
+      const int prow = idx >> 3, ch = idx & 7;
+      const int oy = oy0 + (prow >> 5), ox = ox0 + (prow & 31);
+      if (oy < a.H && ox < a.W)
+        *reinterpret_cast<U4*>(Y + ((size_t)(n * a.H + oy) * a.W + ox) * 64 + ch * 8) =
+            *reinterpret_cast<const U4*>(sC + prow * C_STRIDE + ch * 16);
+    }
+  }
+}
+
+// statistics rows written by one launch (= spatial tiles)
+int dsr_c64_tiles(int N, int H, int W) {
+  return N * ((H + 1) / 2) * ((W + 31) / 32);
+}
+
+void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st) {
+  a.tiles_y = (a.H + 1) / 2;
+  a.tiles_x = (a.W + 31) / 32;
+  a.ntiles = N * a.tiles_y * a.tiles_x;
+  dim3 grid(a.ntiles < 512 ? a.ntiles : 512), block(256);     // persistent, 2 resident blocks per CU
+  if (dtype == DSR_DTYPE_BF16)
+    hipLaunchKernelGGL((conv_c64_kernel<DSR_DTYPE_BF16>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_c64_kernel<DSR_DTYPE_F16>), grid, block, 0, st, a);
+}

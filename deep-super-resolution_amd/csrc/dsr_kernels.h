@@ -100,6 +100,24 @@ struct SmallNArgs {
 };
 int dsr_launch_conv_smalln(SmallNArgs& a, int N, int dtype, hipStream_t st);   // returns 0 if the halo does not fit
 
+// 64 -> 64 channel 3x3 stride-1 zero-pad conv, weights register-resident, persistent (conv_c64.hip)
+struct C64Args {
+  const void* x;       // [N][H][W][64]
+  const void* w;       // [9][64 rows][64]  (rows = output channels of this GEMM)
+  void* y;             // [N][H][W][64]
+  const float* bias;
+  const float* prelu;
+  float* stats;        // [ntiles][2][64]
+  int H, W;
+  int act;
+  float slope;
+  int flags;
+  int tiles_y, tiles_x, ntiles;
+  int tap_y[9], tap_x[9];   // halo-relative row / column offset (0..2) of weight slice t
+};
+int dsr_c64_tiles(int N, int H, int W);
+void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st);
+
 void dsr_launch_wgrad_reduce(const float* partial, float* dw, int splits, int ntaps, int Cout, int Cin, int CoutP,
                              int CinP, hipStream_t st);
 
