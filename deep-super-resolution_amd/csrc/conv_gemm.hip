@@ -19,13 +19,16 @@
 #include "dsr_kernels.h"
 
 template <int DT, int BM, int BN, int WGM, int WGN, bool FAST>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a) {
-  static_assert(WGM * WGN == 4, "4 waves");
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 2) void conv_gemm_kernel(const ConvGemmArgs a) {
+  constexpr int NW = WGM * WGN;                 // 4 or 8 waves; two blocks per CU either way
+  constexpr int NT = 64 * NW;
+  constexpr int RPP = NT / 8;                   // tile rows covered by one pass of the loader (8 lanes per row)
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 16, TN = WN / 16;
   static_assert(TM >= 1 && TN >= 1, "wave tile");
-  constexpr int RA = BM / 32;
-  constexpr int RB = (BN + 31) / 32;
+  constexpr int RA = BM / RPP;
+  constexpr int RB = (BN + RPP - 1) / RPP;
   constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128;
   constexpr int LDS_MAIN = 2 * (A_STAGE + B_STAGE);
   constexpr int C_STRIDE = BN * 2 + 16;
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
   const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  for (int i = tid; i < a.ntaps; i += 256) sTaps[i] = a.taps[i];
+  for (int i = tid; i < a.ntaps; i += NT) sTaps[i] = a.taps[i];
 
   // ---- loader role: unit j of the K-step, rows rb + 32*i
   const int j = tid & 7, rb = tid >> 3;
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
   bool a_ok[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    int m = m0 + rb + 32 * i;
+    int m = m0 + rb + RPP * i;
     a_ok[i] = m < a.M;
     int mm = a_ok[i] ? m : 0;
     int n = fd_div(a.fd_ghw, mm);
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
     // weight rows beyond NB only feed output columns that are never stored: clamp the row instead of predicating
-    const int row = rb + 32 * i;
+    const int row = rb + RPP * i;
     const int co = (n0 + row) < a.NB ? (n0 + row) : a.NB - 1;
     b_base[i] = (co * a.CinP + j * 8) * 2;
   }
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
       }
 #pragma unroll
       for (int i = 0; i < RB; ++i)
-        if (rb + 32 * i < BN)
+        if (rb + RPP * i < BN)
           rbv[i] = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(b_base[i] + woff), 0, 0));
     } else {
     int u = s * 8 + j;
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      int row = rb + 32 * i;
+      int row = rb + RPP * i;
       int co = (n0 + row) < a.NB ? (n0 + row) : a.NB - 1;
       unsigned off = (unsigned)(((widx * a.NB + co) * a.CinP + c8 * 8) * 2);
       if (row < BN) rbv[i] = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, uok ? off : OOB, 0, 0));
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
   int st_off[RA > RB ? RA : RB];
 #pragma unroll
   for (int i = 0; i < (RA > RB ? RA : RB); ++i) {
-    const int row = rb + 32 * i;
+    const int row = rb + RPP * i;
     st_off[i] = row * 128 + ((j ^ (row & 7)) << 4);
   }
   auto store_step = [&](int stage, const U4 (&ra)[RA], const U4 (&rbv)[RB]) {
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     for (int i = 0; i < RA; ++i) *reinterpret_cast<U4*>(sA + stage * A_STAGE + st_off[i]) = ra[i];
 #pragma unroll
     for (int i = 0; i < RB; ++i)
-      if (rb + 32 * i < BN) *reinterpret_cast<U4*>(sB + stage * B_STAGE + st_off[i]) = rbv[i];
+      if (rb + RPP * i < BN) *reinterpret_cast<U4*>(sB + stage * B_STAGE + st_off[i]) = rbv[i];
   };
 
   f32x4 acc[TM][TN];
@@ -175,7 +178,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     const unsigned char* pa = sA + cur * A_STAGE + (wm * WM + r16) * 128;
     const unsigned char* pb = sB + cur * B_STAGE + (wn * WN + r16) * 128;
 #pragma unroll 1
-    for (int kk = 0; kk < 2; ++kk) {   // not unrolled: keeps one set of 8 fragments live instead of two
+    for (int kk = 0; kk < 2; ++kk) {   // rolled: one live set of 8 fragments, so that the depth-2 operand pipeline fits in
+                                       // 256 VGPRs (unrolled it spills inside the loop and measures 10 % slower)
       const int slot = ((4 * kk + g) ^ sw) << 4;
       U4 fa[TM], fb[TN];
 #pragma unroll
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
   __syncthreads();
 
   if (do_stats) {
-    for (int c = tid; c < 2 * BN; c += 256) {
+    for (int c = tid; c < 2 * BN; c += NT) {
       int which = c / BN, ct = c % BN;
       int col = n0 + ct;
       if (col < a.cout) {
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
   unsigned short* __restrict__ Y = reinterpret_cast<unsigned short*>(a.y);
   if (!(a.flags & DSR_F_PIXSHUF)) {
     constexpr int CH = BN / 8;
-    for (int idx = tid; idx < BM * CH; idx += 256) {
+    for (int idx = tid; idx < BM * CH; idx += NT) {
       int row = idx / CH, ch = idx % CH;
       int m = m0 + row, col0 = n0 + ch * 8;
       if (m < a.M && col0 < a.CoutP) {
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     // PixelShuffle(2): conv channel 4c+2i+j of grid pixel (h,w) -> channel c of pixel (2h+i, 2w+j)
     if constexpr (BN >= 32) {
       constexpr int CQ = BN / 32;   // 8-channel output chunks per sub-pixel in this tile
-      for (int idx = tid; idx < BM * 4 * CQ; idx += 256) {
+      for (int idx = tid; idx < BM * 4 * CQ; idx += NT) {
         int row = idx / (4 * CQ);
         int rem2 = idx % (4 * CQ);
         int sub = rem2 / CQ, cq = rem2 % CQ;
@@ -359,7 +363,7 @@ static void launch_one(const ConvGemmArgs& a, hipStream_t st) {
   ConvGemmArgs b = a;
   b.tiles_m = (a.M + BM - 1) / BM;
   b.tiles_n = (a.NB + BN - 1) / BN;
-  dim3 grid(b.tiles_m * b.tiles_n), block(256);
+  dim3 grid(b.tiles_m * b.tiles_n), block(64 * WGM * WGN);
   const bool fast = a.pad_mode == DSR_PAD_ZERO && (a.CU & 7) == 0 && a.ntaps > 0;
   if (fast)
     hipLaunchKernelGGL((conv_gemm_kernel<DT, BM, BN, WGM, WGN, true>), grid, block, 0, st, b);
@@ -372,7 +376,7 @@ int dsr_conv_gemm_bm(int /*NB*/) { return 128; }
 template <int DT>
 static void dispatch_dt(const ConvGemmArgs& a, hipStream_t st) {
   if (a.NB > 64)
-    launch_one<DT, 128, 128, 2, 2>(a, st);
+    launch_one<DT, 128, 128, 2, 2>(a, st);      // (8 waves of 64x32 were tried: LDS-bound, 35 % slower)
   else if (a.NB > 16)
     launch_one<DT, 128, 64, 2, 2>(a, st);
   else
