@@ -43,6 +43,8 @@ WORKLOADS = {
     # name: (batch per GPU, LR size, factor, description)
     "gan_x4": dict(batch=32, lr=128, factor=4, desc="full GAN step x4 (G + D + VGG19 perceptual), batch 32/GPU, 128x128->512x512"),
     "gen_l1_x4": dict(batch=16, lr=32, factor=4, desc="generator-only L1 step x4, batch 16/GPU, 32x32->128x128"),
+    "infer_x8": dict(batch=1, lr=256, factor=8, desc="generator x8 eval forward, fp16, 256x256->2048x2048 (config 5)"),
+    "dip_x2": dict(batch=1, lr=64, factor=2, desc="Deep-Image-Prior iteration x2, HR 128x128, fp16 storage (config 1 on the GPU)"),
 }
 
 
@@ -52,19 +54,39 @@ def conv_flops(d):
     return 2.0 * n * oh * ow * cout * kh * kw * cin
 
 
-def kernel_family(kind, d):
-    cout, cin = d[4], d[3]
-    if kind == "wgrad":
-        return "conv_wgrad_kernel"
-    nb = cin if kind == "dgrad" else cout          # output-column count of the GEMM
-    tile = "128x128" if nb > 64 else ("128x64" if nb > 16 else "128x16")
-    return f"conv_gemm_kernel<{tile}>"
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/*_traffic_<workload>.json, written by tools/pmc_traffic.py); None when no such profile exists.
+    PMC collection needs the profiler around the process, so it cannot be taken live inside the timed run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_traffic_{workload}.json")))
+    if not files:
+        return None
+    fam = json.load(open(files[-1])).get("families", {}).get(kernel)
+    return fam["bytes_per_launch"] if fam else None
 
 
 def build_step(workload, dev, world):
     cfg = WORKLOADS[workload]
     Gm, optim, steps = P("models.GAN.generator"), P("optim"), P("steps")
     torch.manual_seed(0)                      # module-default init under seed 0 (SURVEY.md 8d)
+    if workload == "infer_x8":
+        infer = P("infer")
+        gen = Gm.Generator(8, 16).to(dev)
+        img = torch.rand(1, 3, cfg["lr"], cfg["lr"], generator=torch.Generator().manual_seed(1)).to(dev)
+        return (lambda: infer.super_resolve(gen, img)), (cfg["lr"] * 8) ** 2
+    if workload == "dip_x2":
+        M, Dn = P("models.DIP"), P("utils.downsampler")
+        hr_sz = cfg["lr"] * 2
+        net = M.get_net(32, "skip", "reflection", upsample_mode="bilinear").to(dev).train()
+        down = Dn.Downsampler(3, 2, "lanczos2", phase=0.5, preserve_size=True).to(dev)
+        gcpu = torch.Generator().manual_seed(1)
+        hr_img = torch.rand(1, 3, hr_sz, hr_sz, generator=gcpu).to(dev)
+        with torch.no_grad():
+            lr_img = down(hr_img)
+        z = (torch.rand(1, 32, hr_sz, hr_sz, generator=gcpu) * 0.1).to(dev)
+        run = steps.DipRunner(net, down, z, lr_img, 0.01, 0.05)
+        return (lambda: run.step()[0]), hr_sz * hr_sz
     gen = Gm.Generator(cfg["factor"], 16).to(dev).train()
     n, s, f = cfg["batch"], cfg["lr"], cfg["factor"]
     g = torch.Generator(device="cpu").manual_seed(1 + (dist.get_rank() if world > 1 else 0))
@@ -115,12 +137,35 @@ def host_cores():
 
 def cpu_baseline(workload):
     """The oracle (CPU fp32 restatement of the reference) on a bounded sample of the same workload."""
-    from oracle import filler, gan, recipes, vgg
+    from oracle import dip, downsampler, filler, gan, recipes, vgg
     cores = host_cores()
     torch.set_num_threads(cores)
     cfg = WORKLOADS[workload]
     f = cfg["factor"]
     torch.manual_seed(0)
+    if workload == "infer_x8":
+        s = 128                                  # quarter-size image: the eval forward is linear in pixels
+        gsd = filler.fill_state_dict(gan.template(gan.generator_shapes(8, 16)))
+        x = torch.rand(1, 3, s, s)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            gan.generator_forward(gsd, x, False)
+        dt = time.perf_counter() - t0
+        return {"value": (s * 8) ** 2 / dt / 1e6, "unit": "HR Mpixels/s", "cores": cores, "kind": "port",
+                "sample": f"1 eval forward of a {s}x{s} LR image (workload: 256x256), no warm-up", "seconds_per_step": dt}
+    if workload == "dip_x2":
+        hr_sz = cfg["lr"] * 2
+        dcfg = dip.SkipConfig(input_depth=32)
+        st = recipes.DipState(filler.fill_state_dict(gan.template(dip.skip_shapes(dcfg))), dcfg,
+                              torch.rand(1, 32, hr_sz, hr_sz) * 0.1, factor=2, lr=0.01, reg_noise_std=0.05)
+        lr_img = downsampler.downsampler_forward(torch.rand(1, 3, hr_sz, hr_sz), 2, "lanczos2", phase=0.5, preserve_size=True)
+        recipes.dip_step(st, lr_img)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            recipes.dip_step(st, lr_img)
+        dt = (time.perf_counter() - t0) / 20
+        return {"value": hr_sz * hr_sz / dt / 1e6, "unit": "HR Mpixels/s", "cores": cores, "kind": "port",
+                "sample": "20 iterations after 1 warm-up", "seconds_per_step": dt}
     gsd = filler.fill_state_dict(gan.template(gan.generator_shapes(f, 16)))
     if workload == "gen_l1_x4":
         n, s, reps = cfg["batch"], cfg["lr"], 3
@@ -198,9 +243,11 @@ def main():
     ms = dt / a.steps * 1e3
     value = px_per_rank * world * a.steps / dt / 1e6
 
-    out = {"metric": "HR Mpixels/sec x4 GAN train step", "value": value, "unit": "HR Mpixels/s", "n_gpus": world,
+    metric = {"infer_x8": "HR Mpixels/sec x8 generator inference", "dip_x2": "HR Mpixels/sec DIP iteration"}.get(
+        a.workload, "HR Mpixels/sec x4 GAN train step")
+    out = {"metric": metric, "value": value, "unit": "HR Mpixels/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "vs_baseline": None, "dtype": "f16" if a.workload in ("infer_x8", "dip_x2") else "bf16", "data": "synthetic",
            "config": {"workload": a.workload + ": " + WORKLOADS[a.workload]["desc"],
                       "global_batch": WORKLOADS[a.workload]["batch"] * world, "parallelism": f"dp{world}"}}
 
@@ -212,8 +259,7 @@ def main():
         step()
         torch.cuda.synchronize()
         fam = {}
-        for kind, d, e0, e1 in F.KERNEL_LOG:
-            k = kernel_family(kind, d)
+        for kind, d, e0, e1, k in F.KERNEL_LOG:
             t, fl, cnt = fam.get(k, (0.0, 0.0, 0))
             fam[k] = (t + e0.elapsed_time(e1) * 1e-3, fl + conv_flops(d), cnt + 1)
         F.KERNEL_LOG = None
@@ -222,7 +268,8 @@ def main():
             t, fl, cnt = fam[top]
             ach = fl / t / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": top, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                               "traffic": pmc_traffic(a.workload, top),
                                "launches": cnt, "avg_launch_ms": t / cnt * 1e3,
                                "families": {k: {"seconds": v[0], "tflops": v[1] / v[0] / 1e12, "launches": v[2]}
                                             for k, v in fam.items()}}

@@ -422,3 +422,28 @@ extern "C" int dsr_conv_wgrad(const dsr_conv_desc* d, const void* x, const void*
   dsr_launch_wgrad_reduce(a.partial, dw, a.splits, d->KH * d->KW, d->Cout, d->Cin, a.CoutP, a.CinP, s);
   return dsr_launch_status("dsr_conv_wgrad");
 }
+
+// ---- measurement aid: the kernel family the dispatch above selects (kept next to it so the two cannot drift far)
+static const char* gemm_name(int nb) {
+  return nb > 64 ? "conv_gemm_kernel<128x128>" : (nb > 16 ? "conv_gemm_kernel<128x64>" : "conv_gemm_kernel<128x16>");
+}
+extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, const dsr_epilogue* e) {
+  if (!d || check_desc(d)) return "invalid";
+  const bool ps = e && e->pixel_shuffle, nchw = e && e->out_nchw_f32, stats = e && e->stats_partial;
+  if (op == 0) {
+    if (is_c64(d) && !ps && !nchw) return "conv_c64_kernel";
+    if (d->Cout <= 16 && d->stride == 1 && d->pad_mode == DSR_PAD_ZERO && d->KH * d->KW >= 9 && !stats && !ps &&
+        d->KW == 9 && d->KH <= 9 && r8(d->Cin) == 64)
+      return "conv_smalln_kernel";
+    return gemm_name(r8(d->Cout));
+  }
+  if (op == 1) {
+    if (is_c64(d)) return "conv_c64_kernel";
+    return gemm_name(r8(d->Cin));
+  }
+  WgradTileArgs t;
+  bool taps = false;
+  int ych = tile_plan(d, t, &taps);
+  if (ych > 0) return taps ? "conv_wgrad_taps_kernel" : "conv_wgrad_tile_kernel";
+  return "conv_wgrad_kernel";
+}

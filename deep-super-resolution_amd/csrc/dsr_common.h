@@ -131,6 +131,20 @@ __device__ __forceinline__ f32x4 mfma16(const U4& a, const U4& b, f32x4 c) {
   }
 }
 
+// MFMA 32x32x16: lane l supplies A[m = l%32][k = 8(l/32)..+7] and B[k = 8(l/32)..+7][n = l%32];
+// D[m = 8(i/4) + 4(l/32) + i%4][n = l%32] in register i of 16.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int DT>
+__device__ __forceinline__ f32x16 mfma32(const U4& a, const U4& b, f32x16 c) {
+  if constexpr (DT == DSR_DTYPE_BF16) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
+                                                  0);
+  }
+}
+
 // XCD-aware, bijective block-id remap (consecutive logical tiles share an XCD's L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int nx = 8;

@@ -56,48 +56,83 @@ __global__ void flatten_kernel(const unsigned short* __restrict__ src, unsigned 
 }
 
 // ------------------------------------------------------------------ forward: split-K partials
+// W is [O][K] row-major and the reduction runs along the contiguous axis, so an MFMA operand read straight from
+// global memory puts adjacent lanes on rows 2K bytes apart (64 separate cache lines per load instruction: measured
+// 2.2 TB/s).  Instead the block stages a 256-row x 64-k weight tile (and the 64 x 64 activation tile) through LDS with
+// full-line loads -- 8 adjacent lanes per 128-byte row piece -- and the waves read XOR-swizzled fragments back.
+// Register prefetch of the next stage stays in flight across the compute of the current one.
 template <int DT, int MT>
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const unsigned short* __restrict__ x,
+__global__ __launch_bounds__(512) void linear_fwd_kernel(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ w,
                                                          float* __restrict__ partial, int B, size_t K, int O,
                                                          size_t kchunk) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int WB = 256 * 128;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[WB + 64 * 128];
+  unsigned char* sW = smem;
+  unsigned char* sX = smem + WB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int o = blockIdx.x * 64 + wave * 16 + r;
-  const bool ook = o < O;
+  const int ob = blockIdx.x * 256;
   const size_t k0 = (size_t)blockIdx.y * kchunk;
   size_t k1 = k0 + kchunk;
   if (k1 > K) k1 = K;
-  f32x4 acc[MT];
+  const int lc = tid & 7, lr = tid >> 3;       // loader: chunk lc (8 k) of rows lr + 64 i
+  f32x4 acc[MT][2];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const unsigned short* wrow = w + (size_t)(ook ? o : 0) * K;
-  for (size_t k = k0; k < k1; k += 128) {
-    U4 fb[4], fa[4][MT];
+  for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  U4 vw[4], vx;
+  auto gload = [&](size_t k) {
+    const size_t kk = k + lc * 8;
+    const bool kok = kk < k1;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const size_t kk = k + 32 * u + 8 * g;
-      const bool kok = kk < k1;
-      fb[u] = load16_or_zero(wrow, kk, kok && ook);
+    for (int i = 0; i < 4; ++i) {
+      const int o = ob + lr + 64 * i;
+      vw[i] = load16_or_zero(w, (size_t)o * K + kk, kok && o < O);
+    }
+    vx = load16_or_zero(x, (size_t)lr * K + kk, kok && lr < B);
+  };
+  gload(k0);
+  for (size_t k = k0; k < k1; k += 64) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = lr + 64 * i;
+      *reinterpret_cast<U4*>(sW + row * 128 + ((lc ^ (row & 7)) << 4)) = vw[i];
+    }
+    *reinterpret_cast<U4*>(sX + lr * 128 + ((lc ^ (lr & 7)) << 4)) = vx;
+    __syncthreads();
+    if (k + 64 < k1) gload(k + 64);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = 4 * ks + g;
+      U4 fb[2], fa[MT];
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+        const int row = wave * 32 + nf * 16 + r;
+        fb[nf] = *reinterpret_cast<const U4*>(sW + row * 128 + ((ch ^ (row & 7)) << 4));
+      }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int b = 16 * m + r;
-        fa[u][m] = load16_or_zero(x, (size_t)b * K + kk, kok && b < B);
+        const int row = 16 * m + r;
+        fa[m] = *reinterpret_cast<const U4*>(sX + row * 128 + ((ch ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[m][0] = mfma16<DT>(fa[m], fb[0], acc[m][0]);
+        acc[m][1] = mfma16<DT>(fa[m], fb[1], acc[m][1]);
       }
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = mfma16<DT>(fa[u][m], fb[u], acc[m]);
+    __syncthreads();
   }
   float* P = partial + (size_t)blockIdx.y * B * O;
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int b = 16 * m + 4 * g + j;
-      if (b < B && ook) P[(size_t)b * O + o] = acc[m][j];
-    }
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int b = 16 * m + 4 * g + j, o = ob + wave * 32 + nf * 16 + r;
+        if (b < B && o < O) P[(size_t)b * O + o] = acc[m][nf][j];
+      }
 }
 
 // out[b][o] = act(sum_s partial[s][b][o] + bias[o])   (fp32)
@@ -116,94 +151,137 @@ __device__ __forceinline__ s16x4 lds_tr_read16(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
+// Block = 128 k-columns; the O rows stream through a double-buffered LDS stage of 32 rows (W: 32 x 256 B, XOR-swizzled
+// 16-byte chunks; dy: 64 x 64 B padded to 80).  Global loads for stage s+1 are issued before stage s is computed and
+// land in the other buffer afterwards: one barrier per stage, loads always in flight.
+// k-slot mapping of one 32-row stage (fixed by the transposing read): slots 0-3 of lane group g <-> rows 4g..4g+3,
+// slots 4-7 <-> rows 16+4g..16+4g+3.
 template <int DT, int MT>
 __global__ __launch_bounds__(256) void linear_dgrad_kernel(const unsigned short* __restrict__ dy,
                                                            const unsigned short* __restrict__ w,
                                                            unsigned short* __restrict__ dx, int B, int O, size_t K) {
-  __shared__ __attribute__((aligned(16))) unsigned char sW[64 * 128];   // [64 o][64 k] 16-bit, XOR-swizzled chunks
+  constexpr int WB = 32 * 256, YB = 64 * 80;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (WB + YB)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, g = lane >> 4;
-  const size_t kb = (size_t)blockIdx.x * 64;
-  const int c = tid & 7, rr = tid >> 3;   // loader: chunk c (8 k), rows rr and rr+32
+  const size_t kb = (size_t)blockIdx.x * 128;
+  const int c = tid & 15, rr = tid >> 4;        // W loader: 16-byte chunk c of rows rr and rr+16
   const bool kok = (kb + c * 8) < K;
-  f32x4 acc[MT];
+  const int yb = tid >> 2, yc = tid & 3;        // dy loader: batch row yb, chunk yc (8 outputs)
+  const bool ybok = yb < B;
+  f32x4 acc[MT][2];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int q = l16 >> 2, cc = 4 * (l16 & 3);
-  const int col = wave * 16 + cc;                    // first of this lane's 4 k-columns inside the tile
-  const int chunk = col >> 3, within = (col & 7) * 2;
-  for (int o0 = 0; o0 < O; o0 += 64) {
-    U4 v0 = load16_or_zero(w, (size_t)(o0 + rr) * K + kb + c * 8, kok && (o0 + rr) < O);
-    U4 v1 = load16_or_zero(w, (size_t)(o0 + rr + 32) * K + kb + c * 8, kok && (o0 + rr + 32) < O);
-    __syncthreads();
-    *reinterpret_cast<U4*>(sW + rr * 128 + ((c ^ (rr & 7)) << 4)) = v0;
-    *reinterpret_cast<U4*>(sW + (rr + 32) * 128 + ((c ^ ((rr + 32) & 7)) << 4)) = v1;
-    __syncthreads();
+  U4 v0, v1, vy;
+  auto gload = [&](int o0) {
+    v0 = load16_or_zero(w, (size_t)(o0 + rr) * K + kb + c * 8, kok && (o0 + rr) < O);
+    v1 = load16_or_zero(w, (size_t)(o0 + rr + 16) * K + kb + c * 8, kok && (o0 + rr + 16) < O);
+    vy = load16_or_zero(dy, (size_t)yb * O + o0 + yc * 8, ybok && (o0 + yc * 8) < O);
+  };
+  auto sstore = [&](int buf) {
+    unsigned char* sW = smem + buf * (WB + YB);
+    unsigned char* sY = sW + WB;
+    *reinterpret_cast<U4*>(sW + rr * 256 + ((c ^ (rr & 15)) << 4)) = v0;
+    *reinterpret_cast<U4*>(sW + (rr + 16) * 256 + ((c ^ ((rr + 16) & 15)) << 4)) = v1;
+    *reinterpret_cast<U4*>(sY + yb * 80 + yc * 16) = vy;
+  };
+  const int nstage = (O + 31) / 32;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int s = 0; s < nstage; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nstage) gload(32 * (s + 1));
+    const unsigned char* sW = smem + buf * (WB + YB);
+    const unsigned char* sY = sW + WB;
+    U4 fb[2];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      const int p1 = 32 * sub + 4 * g + q, p2 = p1 + 16;
-      s16x4 b1 = lds_tr_read16(sW + p1 * 128 + ((chunk ^ (p1 & 7)) << 4) + within);
-      s16x4 b2 = lds_tr_read16(sW + p2 * 128 + ((chunk ^ (p2 & 7)) << 4) + within);
-      U4 fb = __builtin_bit_cast(U4, __builtin_shufflevector(b1, b2, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int b = 16 * m + l16;
-        const int oa = o0 + 32 * sub + 4 * g;   // this lane's k-slots: o = oa..oa+3 and oa+16..oa+19
-        const bool ok = b < B;
-        const unsigned short* row = dy + (size_t)(ok ? b : 0) * O;
-        uint2 a1 = *reinterpret_cast<const uint2*>(row + (oa < O ? oa : 0));
-        uint2 a2 = *reinterpret_cast<const uint2*>(row + (oa + 16 < O ? oa + 16 : 0));
-        U4 fa;
-        fa.x = (ok && oa < O) ? a1.x : 0u;
-        fa.y = (ok && oa < O) ? a1.y : 0u;
-        fa.z = (ok && oa + 16 < O) ? a2.x : 0u;
-        fa.w = (ok && oa + 16 < O) ? a2.y : 0u;
-        acc[m] = mfma16<DT>(fa, fb, acc[m]);
-      }
+    for (int nf = 0; nf < 2; ++nf) {
+      const int col = wave * 32 + nf * 16 + cc;
+      const int chunk = col >> 3, within = (col & 7) * 2;
+      const int p1 = 4 * g + q, p2 = p1 + 16;
+      s16x4 b1 = lds_tr_read16(sW + p1 * 256 + ((chunk ^ (p1 & 15)) << 4) + within);
+      s16x4 b2 = lds_tr_read16(sW + p2 * 256 + ((chunk ^ (p2 & 15)) << 4) + within);
+      fb[nf] = __builtin_bit_cast(U4, __builtin_shufflevector(b1, b2, 0, 1, 2, 3, 4, 5, 6, 7));
     }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const unsigned char* row = sY + (16 * m + l16) * 80;
+      const uint2 a1 = *reinterpret_cast<const uint2*>(row + 8 * g);
+      const uint2 a2 = *reinterpret_cast<const uint2*>(row + 32 + 8 * g);
+      U4 fa = {a1.x, a1.y, a2.x, a2.y};
+      acc[m][0] = mfma16<DT>(fa, fb[0], acc[m][0]);
+      acc[m][1] = mfma16<DT>(fa, fb[1], acc[m][1]);
+    }
+    if (s + 1 < nstage) sstore(buf ^ 1);
+    __syncthreads();
   }
-  const size_t k = kb + wave * 16 + l16;
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int b = 16 * m + 4 * g + j;
-      if (b < B && k < K) dx[(size_t)b * K + k] = f2h<DT>(acc[m][j]);
+    for (int nf = 0; nf < 2; ++nf) {
+      const size_t k = kb + wave * 32 + nf * 16 + l16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int b = 16 * m + 4 * g + j;
+        if (b < B && k < K) dx[(size_t)b * K + k] = f2h<DT>(acc[m][nf][j]);
+      }
     }
 }
 
 // ------------------------------------------------------------------ wgrad: dW[o][k] = sum_b dyT[o][b] xT[k][b]
-// D[m = k][n = o]: a lane ends up with 4 consecutive k of one o -> one 16-byte fp32 store.
+// 32x32x16 MFMA with D[m = o][n = k]: the 32 lanes of a half-wave hold 32 consecutive k of one output row, so every
+// store instruction writes two full 128-byte lines (a 16x16 tile would write 64-byte pieces, which the memory side
+// turns into read-modify-write).  A wave keeps its 64 x BP slice of dyT in registers and streams xT.
 template <int DT, int BP>
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const unsigned short* __restrict__ dyT,
                                                            const unsigned short* __restrict__ xT,
                                                            float* __restrict__ dw, int O, size_t K, int ktiles_per_block) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, g = lane >> 4;
-  const int o = blockIdx.y * 64 + wave * 16 + r;
-  const bool ook = o < O;
-  constexpr int KS = BP / 32;
-  U4 fb[KS];
+  const int r = lane & 31, hf = lane >> 5;
+  const int o0 = blockIdx.y * 256 + wave * 64;
+  if (o0 >= O) return;
+  constexpr int KS = BP / 16;
+  U4 fa[2][KS];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) fb[s] = load16_or_zero(dyT, (size_t)o * BP + 32 * s + 8 * g, ook);
+  for (int mf = 0; mf < 2; ++mf) {
+    const int o = o0 + 32 * mf + r;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) fa[mf][s] = load16_or_zero(dyT, (size_t)o * BP + 16 * s + 8 * hf, o < O);
+  }
   const size_t kt0 = (size_t)blockIdx.x * ktiles_per_block;
-  for (int t = 0; t < ktiles_per_block; ++t) {
-    const size_t kbase = (kt0 + t) * 16;
-    if (kbase >= K) break;
-    const size_t krow = kbase + r;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  U4 fb[KS], fn[KS];
+  {
+    const size_t krow = kt0 * 32 + r;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      U4 fa = load16_or_zero(xT, krow * BP + 32 * s + 8 * g, krow < K);
-      acc = mfma16<DT>(fa, fb[s], acc);
+    for (int s = 0; s < KS; ++s) fb[s] = load16_or_zero(xT, krow * BP + 16 * s + 8 * hf, krow < K);
+  }
+  for (int t = 0; t < ktiles_per_block; ++t) {
+    const size_t kbase = (kt0 + t) * 32;
+    if (kbase >= K) break;
+    {
+      const size_t krow = kbase + 32 + r;
+      const bool ok = (t + 1 < ktiles_per_block) && krow < K;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) fn[s] = load16_or_zero(xT, krow * BP + 16 * s + 8 * hf, ok);
     }
-    const size_t k = kbase + 4 * g;   // rows 4g..4g+3 of the tile = 4 consecutive k, column r = output o
-    if (ook && k + 3 < K) {
-      *reinterpret_cast<float4*>(dw + (size_t)o * K + k) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    } else if (ook) {
-      for (int j = 0; j < 4; ++j)
-        if (k + j < K) dw[(size_t)o * K + k + j] = acc[j];
+    const size_t k = kbase + r;
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc = mfma32<DT>(fa[mf][s], fb[s], acc);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int o = o0 + 32 * mf + 8 * (i >> 2) + 4 * hf + (i & 3);
+        if (o < O && k < K) dw[(size_t)o * K + k] = acc[i];
+      }
     }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) fb[s] = fn[s];
   }
 }
 
@@ -285,8 +363,8 @@ extern "C" int dsr_flatten(int dtype, const void* src, void* dst, int B, int HW,
 }
 
 static int linear_splits(size_t K, int O, size_t* kchunk) {
-  long long otiles = (O + 63) / 64;
-  long long want = (2048 + otiles - 1) / otiles;
+  long long otiles = (O + 255) / 256;
+  long long want = (768 + otiles - 1) / otiles;          // three 8-wave blocks per CU
   long long maxs = (long long)((K + 1023) / 1024);
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -309,7 +387,7 @@ extern "C" int dsr_linear_fwd(int dtype, const void* x, const void* w16, const f
   size_t ch;
   int S = linear_splits(K, O, &ch);
   if (!workspace || ws_bytes < (size_t)S * B * O * sizeof(float)) return dsr_fail(DSR_E_WORKSPACE, "linear_fwd: workspace");
-  dim3 grid((O + 63) / 64, S), block(256);
+  dim3 grid((O + 255) / 256, S), block(512);
   const unsigned short* X = (const unsigned short*)x;
   const unsigned short* W = (const unsigned short*)w16;
   float* P = (float*)workspace;
@@ -328,8 +406,8 @@ extern "C" int dsr_linear_fwd(int dtype, const void* x, const void* w16, const f
 extern "C" int dsr_linear_dgrad(int dtype, const void* dy16, const void* w16, void* dx, int B, int O, size_t K,
                                 dsr_stream_t st) {
   if (B < 1 || B > 64) return dsr_fail(DSR_E_UNSUPPORTED, "linear: batch %d outside 1..64", B);
-  if (K % 8 || O % 4) return dsr_fail(DSR_E_ARG, "linear_dgrad: K %% 8 or O %% 4");
-  dim3 grid((unsigned)((K + 63) / 64)), block(256);
+  if (K % 8 || O % 8) return dsr_fail(DSR_E_ARG, "linear_dgrad: K %% 8 or O %% 8");
+  dim3 grid((unsigned)((K + 127) / 128)), block(256);
   const unsigned short* DY = (const unsigned short*)dy16;
   const unsigned short* W = (const unsigned short*)w16;
   unsigned short* DX = (unsigned short*)dx;
@@ -347,9 +425,9 @@ extern "C" int dsr_linear_wgrad(int dtype, const void* dyT16, const void* xT16, 
                                 dsr_stream_t st) {
   if (Bp != 32 && Bp != 64) return dsr_fail(DSR_E_UNSUPPORTED, "linear_wgrad: padded batch must be 32 or 64");
   if (K % 4) return dsr_fail(DSR_E_ARG, "linear_wgrad: K %% 4");
-  const int tpb = 64;   // 16-wide k tiles per block -> 1024 k per block
-  size_t ktiles = (K + 15) / 16;
-  dim3 grid((unsigned)((ktiles + tpb - 1) / tpb), (O + 63) / 64), block(256);
+  const int tpb = 16;   // 32-wide k tiles per block -> 512 k per block
+  size_t ktiles = (K + 31) / 32;
+  dim3 grid((unsigned)((ktiles + tpb - 1) / tpb), (O + 255) / 256), block(256);
   const unsigned short* DYT = (const unsigned short*)dyT16;
   const unsigned short* XT = (const unsigned short*)xT16;
 #define LAUNCH_WG(DTV, BPV) hipLaunchKernelGGL((linear_wgrad_kernel<DTV, BPV>), grid, block, 0, st, DYT, XT, dw, O, K, tpb)

@@ -51,7 +51,10 @@ def _need_gpu(t):
 KERNEL_LOG = None          # set to a list to record (kind, desc-tuple, start_event, end_event) per conv launch
 
 
-def _timed(kind, desc, fn):
+_OPS = {"fwd": 0, "dgrad": 1, "wgrad": 2}
+
+
+def _timed(kind, desc, fn, ep=None):
     """Run one C-ABI conv call; when KERNEL_LOG is a list, bracket it with HIP events on the launch stream."""
     if KERNEL_LOG is None:
         return fn()
@@ -59,7 +62,8 @@ def _timed(kind, desc, fn):
     e0.record()
     rc = fn()
     e1.record()
-    KERNEL_LOG.append((kind, (desc.N, desc.H, desc.W, desc.Cin, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad), e0, e1))
+    name = _lib.lib().dsr_conv_kernel_name(C.byref(desc), _OPS[kind], C.byref(ep) if ep is not None else None).decode()
+    KERNEL_LOG.append((kind, (desc.N, desc.H, desc.W, desc.Cin, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad), e0, e1, name))
     return rc
 
 
@@ -227,7 +231,7 @@ class ConvAct(torch.autograd.Function):
         act = cfg.get("act", ACT_NONE)
         ep = Epilogue(act, float(cfg.get("slope", 0.0)), _ptr(prelu), _ptr(bias), None, int(ps), None)
         check(_timed("fwd", desc, lambda: _lib.lib().dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y),
-                                                                    _stream())))
+                                                                    _stream()), ep))
         ctx.desc, ctx.cfg, ctx.ps, ctx.act = desc, cfg, ps, act
         ctx.wshape = tuple(weight.shape)
         ctx.has_bias = bias is not None
@@ -305,7 +309,7 @@ class ConvBNAct(torch.autograd.Function):
             part = torch.empty((rows + _scr()) * 2 * cp, dtype=torch.float32, device=dev)
             ep = Epilogue(ACT_NONE, 0.0, None, _ptr(bias), _ptr(part), 0, None)
             check(_timed("fwd", desc, lambda: lib.dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y),
-                                                                 _stream())))
+                                                                 _stream()), ep))
             check(lib.dsr_pw_bn_finalize(_ptr(part), rows, cp, cout, cp, float(count), _ptr(gamma), _ptr(beta),
                                          _ptr(running_mean), _ptr(running_var), _ptr(nbt), BN_MOMENTUM, BN_EPS,
                                          int(cfg.get("bn_updates", 1)),
@@ -313,7 +317,7 @@ class ConvBNAct(torch.autograd.Function):
         else:
             ep = Epilogue(ACT_NONE, 0.0, None, _ptr(bias), None, 0, None)
             check(_timed("fwd", desc, lambda: lib.dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y),
-                                                                 _stream())))
+                                                                 _stream()), ep))
             check(lib.dsr_pw_bn_eval_affine(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), BN_EPS,
                                             cout, cp, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
         act = cfg.get("act", ACT_NONE)
@@ -383,7 +387,7 @@ class ConvOutNCHW(torch.autograd.Function):
         act = cfg.get("act", ACT_NONE)
         ep = Epilogue(act, 0.0, None, _ptr(bias), None, 0, _ptr(out))
         check(_timed("fwd", desc, lambda: _lib.lib().dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), None,
-                                                                    _stream())))
+                                                                    _stream()), ep))
         ctx.desc, ctx.act = desc, act
         ctx.wshape = tuple(weight.shape)
         ctx.has_bias = bias is not None

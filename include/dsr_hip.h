@@ -82,6 +82,11 @@ size_t dsr_conv_wgrad_workspace(const dsr_conv_desc* d);
 int dsr_conv_wgrad(const dsr_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes,
                    dsr_stream_t s);
 
+/* Which kernel the dispatcher launches for this descriptor (measurement aid: bench.py labels its HIP-event timings
+ * with it so they can be matched against rocprofv3's kernel names).  op: 0 forward, 1 dgrad, 2 wgrad.  `e` may be
+ * NULL (no statistics, no pixel shuffle, NHWC output).  Returns a static string; never NULL. */
+const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, const dsr_epilogue* e);
+
 /* ------------------------------------------------------------------ pointwise / reductions (pointwise.hip)
  * nn.BatchNorm2d / PReLU / LeakyReLU / Tanh / Sigmoid / residual add / PixelShuffle backward / losses / Adam.
  * See the kernel comments in csrc/pointwise.hip for the reference lines each covers. */

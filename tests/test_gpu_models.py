@@ -78,6 +78,47 @@ def test_dense_head(dev, n):
         assert rel_err(got.grad.cpu(), ref.grad) < 2e-2, name
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("b,k,o", [(37, 1000, 72), (64, 4104, 1024), (3, 264, 8), (32, 33000, 1032)])
+def test_linear_kernels_ragged(dev, dtype, b, k, o):
+    """dsr_linear_{fwd,dgrad,wgrad} through the C ABI at sizes that are not multiples of any tile (dense1 of
+    discriminator.py:41 is 64 x 524288 x 1024; these shapes exercise every edge guard) against fp64 matmuls."""
+    import ctypes as C
+    L = P("_lib")
+    lib = L.lib()
+    dt = 0 if dtype == torch.bfloat16 else 1
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = filler.tensor("lin:x", (b, k)).to(dtype)
+    w = filler.tensor("lin:w", (o, k), float(np.sqrt(3.0 / k))).to(dtype)
+    dy = filler.tensor("lin:dy", (b, o)).to(dtype)
+    bias = filler.tensor("lin:b", (o,), 0.1)
+    xd, wd, dyd, bd = x.to(dev), w.to(dev), dy.to(dev), bias.to(dev)
+    # forward
+    wsz = lib.dsr_linear_fwd_workspace(b, k, o)
+    ws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=dev)
+    out = torch.empty((b, o), dtype=torch.float32, device=dev)
+    L.check(lib.dsr_linear_fwd(dt, ptr(xd), ptr(wd), ptr(bd), 1, 0.2, ptr(out), b, k, o, ptr(ws), wsz, st))
+    ref = TF.leaky_relu(x.double() @ w.double().t() + bias.double(), 0.2)
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    # dgrad
+    dx = torch.full((b, k), float("nan"), dtype=dtype, device=dev)
+    L.check(lib.dsr_linear_dgrad(dt, ptr(dyd), ptr(wd), ptr(dx), b, o, k, st))
+    ref = dy.double() @ w.double()
+    tol = (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11) * ref.abs().max().item() + 1e-6
+    assert (dx.cpu().double() - ref).abs().max().item() <= tol
+    # wgrad (batch-minor operands, batch padded to 32 | 64)
+    bp = 32 if b <= 32 else 64
+    dyt = torch.zeros((o, bp), dtype=dtype, device=dev)
+    dyt[:, :b] = dyd.t()
+    xt = torch.zeros((k, bp), dtype=dtype, device=dev)
+    xt[:, :b] = xd.t()
+    dw = torch.full((o, k), float("nan"), dtype=torch.float32, device=dev)
+    L.check(lib.dsr_linear_wgrad(dt, ptr(dyt), ptr(xt), ptr(dw), bp, o, k, st))
+    ref = dy.double().t() @ x.double()
+    assert (dw.cpu().double() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+
+
 def test_maxpool_bilinear_concat(dev):
     F = P("functional")
     x = bfr(filler.tensor("mp:x", (2, 16, 6, 10)))
