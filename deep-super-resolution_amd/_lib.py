@@ -62,6 +62,7 @@ SIGNATURES = {
     "dsr_pw_diff_loss": (_I, [_P, _P, _P, _Z, _I, _P, _I, _P]),
     "dsr_pw_bce_const": (_I, [_P, _I, _F, _P, _P, _I, _P]),
     "dsr_pw_adam": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P, _F, _P, _P]),
+    "dsr_pw_adam_multi": (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P, _F, _P]),
     "dsr_pw_incr": (_I, [_P, _P]),
     "dsr_cast16": (_I, [_I, _P, _P, _Z, _P]),
     "dsr_flatten": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

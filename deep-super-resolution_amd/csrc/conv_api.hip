@@ -56,6 +56,14 @@ extern "C" int dsr_conv_out_size(const dsr_conv_desc* d, int* OH, int* OW) {
   return DSR_OK;
 }
 
+static bool is_cin8(const dsr_conv_desc* d, const dsr_epilogue* e) {   // first layer: RGB (padded to 8) -> 64, 3x3 s1 p1
+  return d->Cin <= 8 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
+         d->pad_mode == DSR_PAD_ZERO && !(e && (e->stats_partial || e->pixel_shuffle || e->out_nchw_f32));
+}
+static bool is_smalln_dgrad(const dsr_conv_desc* d) {
+  return d->Cin <= 16 && r8(d->Cout) == 64 && d->stride == 1 && d->pad_mode == DSR_PAD_ZERO && d->KH == d->KW &&
+         (d->KW == 3 || d->KW == 9) && 2 * d->pad == d->KH - 1;
+}
 static bool is_c64(const dsr_conv_desc* d) {
   return d->Cin == 64 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
          d->pad_mode == DSR_PAD_ZERO;
@@ -164,6 +172,21 @@ extern "C" int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w
       }
     dsr_launch_conv_c64(c, d->N, d->dtype, s);
     return dsr_launch_status("dsr_conv_fwd(c64)");
+  }
+  if (is_cin8(d, e)) {
+    Cin8Args c;
+    memset(&c, 0, sizeof(c));
+    c.x = x;
+    c.w = w_fwd;
+    c.y = y;
+    c.bias = e->bias;
+    c.prelu = (e->act == DSR_ACT_PRELU) ? e->prelu : nullptr;
+    c.H = d->H;
+    c.W = d->W;
+    c.act = e->act;
+    c.slope = e->slope;
+    dsr_launch_conv_cin8(c, d->N, d->dtype, s);
+    return dsr_launch_status("dsr_conv_fwd(cin8)");
   }
   if (d->Cout <= 16 && d->stride == 1 && d->pad_mode == DSR_PAD_ZERO && d->KH * d->KW >= 9 && !e->stats_partial &&
       !e->pixel_shuffle) {
@@ -274,6 +297,29 @@ extern "C" int dsr_conv_dgrad(const dsr_conv_desc* d, const void* dy, const void
       }
     dsr_launch_conv_c64(c, d->N, d->dtype, s);
     return dsr_launch_status("dsr_conv_dgrad(c64)");
+  }
+  if (is_smalln_dgrad(d)) {
+    // few input channels (the RGB first layers, discriminator.py:22): dx = dy correlated with the mirrored kernel,
+    // a stride-1 "forward" problem with Cin output channels -> the halo-staged small-N kernel
+    SmallNArgs sn;
+    memset(&sn, 0, sizeof(sn));
+    sn.x = dy;
+    sn.w = w_dgrad;
+    sn.y = dx;
+    sn.IH = OH;
+    sn.IW = OW;
+    sn.CinP = r8(d->Cout);
+    sn.OH = d->H;
+    sn.OW = d->W;
+    sn.CoutP = r8(d->Cin);
+    sn.NB = r8(d->Cin);
+    sn.cout = d->Cin;
+    sn.KH = d->KH;
+    sn.KW = d->KW;
+    sn.pad = d->KH - 1 - d->pad;
+    sn.act = DSR_ACT_NONE;
+    sn.flip = 1;
+    if (dsr_launch_conv_smalln(sn, d->N, d->dtype, s)) return dsr_launch_status("dsr_conv_dgrad(small-n)");
   }
   const int st = d->stride;
   for (int ph = 0; ph < st; ++ph)
@@ -432,6 +478,7 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
   const bool ps = e && e->pixel_shuffle, nchw = e && e->out_nchw_f32, stats = e && e->stats_partial;
   if (op == 0) {
     if (is_c64(d) && !ps && !nchw) return "conv_c64_kernel";
+    if (is_cin8(d, e)) return "conv_cin8_kernel";
     if (d->Cout <= 16 && d->stride == 1 && d->pad_mode == DSR_PAD_ZERO && d->KH * d->KW >= 9 && !stats && !ps &&
         d->KW == 9 && d->KH <= 9 && r8(d->Cin) == 64)
       return "conv_smalln_kernel";
@@ -439,6 +486,7 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
   }
   if (op == 1) {
     if (is_c64(d)) return "conv_c64_kernel";
+    if (is_smalln_dgrad(d)) return "conv_smalln_kernel";
     return gemm_name(r8(d->Cin));
   }
   WgradTileArgs t;

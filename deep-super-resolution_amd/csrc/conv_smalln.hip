@@ -34,7 +34,8 @@ __global__ __launch_bounds__(512, 2) void conv_smalln_kernel(const SmallNArgs a)
 
   for (int i = tid; i < ntaps * WR * 8; i += 512) {      // global [tap][NB][64] 16-bit -> LDS [tap][WR][64]
     const int ch = i & 7, row = (i >> 3) % WR, tap = (i >> 3) / WR;
-    reinterpret_cast<U4*>(sW)[i] = reinterpret_cast<const U4*>(W)[(tap * a.NB + row) * 8 + ch];
+    const int src = a.flip ? ntaps - 1 - tap : tap;      // dgrad: mirrored taps of the [tap][ci][co] image
+    reinterpret_cast<U4*>(sW)[i] = reinterpret_cast<const U4*>(W)[(src * a.NB + row) * 8 + ch];
   }
   const int wrow = r16 < WR ? r16 : 0;
   const int w_off = wrow * 128 + g * 16;                 // + tap * WR*128 + kk*64
@@ -50,6 +51,10 @@ __global__ __launch_bounds__(512, 2) void conv_smalln_kernel(const SmallNArgs a)
   //  loop needs those registers to keep several LDS reads in flight ahead of the MFMAs)
   const int hr0 = pb / HC, hc0 = pb - hr0 * HC;
   U4 v[NV];
+  // buffer loads (out-of-range offset -> zeros): a select on the loaded data would pin the wait for this prefetch
+  // right behind its issue, in front of the tap loop it is meant to run under
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
   auto fetch = [&](int t) {
     const int n = t / per_img;
     const int rem = t - n * per_img;
@@ -59,7 +64,8 @@ __global__ __launch_bounds__(512, 2) void conv_smalln_kernel(const SmallNArgs a)
     for (int u = 0; u < NV; ++u) {
       const int iy = oy0 + hr, ix = ox0 + hc;
       const bool ok = hr < HR && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-      v[u] = load16_or_zero(X, ((size_t)(n * a.IH + iy) * a.IW + ix) * a.CinP + c * 8, ok);
+      v[u] = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(
+                                        xrsrc, ok ? (unsigned)((((n * a.IH + iy) * a.IW + ix) * 64 + c * 8) * 2) : OOB, 0, 0));
       hc += 64;
       while (hc >= HC) {
         hc -= HC;
@@ -159,34 +165,45 @@ __global__ void zero_pad_channels_kernel(unsigned short* __restrict__ y, size_t 
   for (int c = cout; c < CoutP; ++c) y[p * CoutP + c] = 0;
 }
 
-static bool g_smalln_attr_set[2] = {false, false};
+static bool g_smalln_attr_set[4] = {false, false, false, false};
 
 int dsr_launch_conv_smalln(SmallNArgs& a, int N, int dtype, hipStream_t st) {
   a.tiles_y = (a.OH + 7) / 8;
   a.tiles_x = (a.OW + 31) / 32;
   const int HR = 8 + a.KH - 1, HC = (32 + a.KW - 1 + 7) & ~7;
   const size_t lds = (size_t)HR * HC * 128 + (size_t)a.KH * a.KW * ((a.cout + 3) & ~3) * 128;
-  if (lds > 160 * 1024 || a.KW != 9 || a.KH > 9 || a.CinP != 64) return 0;
+  if (lds > 160 * 1024 || (a.KW != 9 && a.KW != 3) || a.KH > 9 || a.CinP != 64) return 0;
   a.ntiles = N * a.tiles_y * a.tiles_x;
-  dim3 grid(a.ntiles < 256 ? a.ntiles : 256), block(512);   // persistent: one 8-wave block per CU
-  const int di = dtype == DSR_DTYPE_BF16 ? 0 : 1;
+  a.x_bytes = (unsigned)((size_t)N * a.IH * a.IW * 128);
+  const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+  dim3 grid(a.ntiles < 256 * per_cu ? a.ntiles : 256 * per_cu), block(512);   // persistent 8-wave blocks
+  const int di = (dtype == DSR_DTYPE_BF16 ? 0 : 1) + (a.KW == 9 ? 0 : 2);
+  const void* fn = di == 0   ? (const void*)conv_smalln_kernel<DSR_DTYPE_BF16, 9>
+                   : di == 1 ? (const void*)conv_smalln_kernel<DSR_DTYPE_F16, 9>
+                   : di == 2 ? (const void*)conv_smalln_kernel<DSR_DTYPE_BF16, 3>
+                             : (const void*)conv_smalln_kernel<DSR_DTYPE_F16, 3>;
   if (!g_smalln_attr_set[di]) {   // > 64 KB of dynamic LDS needs the opt-in once per kernel (not a stream operation)
-    if (di == 0)
-      hipFuncSetAttribute((const void*)conv_smalln_kernel<DSR_DTYPE_BF16, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    else
-      hipFuncSetAttribute((const void*)conv_smalln_kernel<DSR_DTYPE_F16, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     g_smalln_attr_set[di] = true;
   }
+  const size_t P = (size_t)N * a.OH * a.OW;
+  const bool zpad = !a.out_f32 && a.cout < a.CoutP;
   if (dtype == DSR_DTYPE_BF16) {
-    hipLaunchKernelGGL((conv_smalln_kernel<DSR_DTYPE_BF16, 9>), grid, block, lds, st, a);
-    if (!a.out_f32 && a.cout < a.CoutP)
-      hipLaunchKernelGGL((zero_pad_channels_kernel<DSR_DTYPE_BF16>), dim3((unsigned)(((size_t)N * a.OH * a.OW + 255) / 256)),
-                         dim3(256), 0, st, (unsigned short*)a.y, (size_t)N * a.OH * a.OW, a.cout, a.CoutP);
+    if (a.KW == 9)
+      hipLaunchKernelGGL((conv_smalln_kernel<DSR_DTYPE_BF16, 9>), grid, block, lds, st, a);
+    else
+      hipLaunchKernelGGL((conv_smalln_kernel<DSR_DTYPE_BF16, 3>), grid, block, lds, st, a);
+    if (zpad)
+      hipLaunchKernelGGL((zero_pad_channels_kernel<DSR_DTYPE_BF16>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
+                         (unsigned short*)a.y, P, a.cout, a.CoutP);
   } else {
-    hipLaunchKernelGGL((conv_smalln_kernel<DSR_DTYPE_F16, 9>), grid, block, lds, st, a);
-    if (!a.out_f32 && a.cout < a.CoutP)
-      hipLaunchKernelGGL((zero_pad_channels_kernel<DSR_DTYPE_F16>), dim3((unsigned)(((size_t)N * a.OH * a.OW + 255) / 256)),
-                         dim3(256), 0, st, (unsigned short*)a.y, (size_t)N * a.OH * a.OW, a.cout, a.CoutP);
+    if (a.KW == 9)
+      hipLaunchKernelGGL((conv_smalln_kernel<DSR_DTYPE_F16, 9>), grid, block, lds, st, a);
+    else
+      hipLaunchKernelGGL((conv_smalln_kernel<DSR_DTYPE_F16, 3>), grid, block, lds, st, a);
+    if (zpad)
+      hipLaunchKernelGGL((zero_pad_channels_kernel<DSR_DTYPE_F16>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
+                         (unsigned short*)a.y, P, a.cout, a.CoutP);
   }
   return 1;
 }

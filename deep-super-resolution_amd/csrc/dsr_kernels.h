@@ -97,6 +97,8 @@ struct SmallNArgs {
   int IH, IW, CinP, OH, OW, CoutP, NB, cout, KH, KW, pad, act;
   float slope;
   int tiles_y, tiles_x, ntiles;
+  int flip;           // read weight slice ntaps-1-t for tap t (input gradient = correlation with the mirrored kernel)
+  unsigned x_bytes;
 };
 int dsr_launch_conv_smalln(SmallNArgs& a, int N, int dtype, hipStream_t st);   // returns 0 if the halo does not fit
 
@@ -117,6 +119,20 @@ struct C64Args {
 };
 int dsr_c64_tiles(int N, int H, int W);
 void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st);
+
+struct Cin8Args {
+  const void* x;       // [N][H][W][8]
+  const void* w;       // forward weight image [9][64][8]
+  void* y;             // [N][H][W][64]
+  const float* bias;
+  const float* prelu;
+  int H, W;
+  int act;
+  float slope;
+  int tiles_y, tiles_x, ntiles;
+  unsigned x_bytes;
+};
+void dsr_launch_conv_cin8(Cin8Args& a, int N, int dtype, hipStream_t st);
 
 void dsr_launch_wgrad_reduce(const float* partial, float* dw, int splits, int ntaps, int Cout, int Cin, int CoutP,
                              int CinP, hipStream_t st);

@@ -795,6 +795,65 @@ extern "C" int dsr_pw_adam(float* p, const float* g, float* m, float* v, size_t 
                      (unsigned short*)shadow_bf16);
   return dsr_launch_status("dsr_pw_adam");
 }
+// ---- multi-tensor Adam: the generator and discriminator hold ~100 small tensors each; one launch per 64 of them.
+#define DSR_ADAM_GROUP 64
+#define DSR_ADAM_CHUNK 4096   // elements per block
+struct AdamGroup {
+  float* p[DSR_ADAM_GROUP];
+  const float* g[DSR_ADAM_GROUP];
+  float* m[DSR_ADAM_GROUP];
+  float* v[DSR_ADAM_GROUP];
+  unsigned n[DSR_ADAM_GROUP];
+  unsigned first_block[DSR_ADAM_GROUP + 1];
+  int count;
+};
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamGroup a, float lr, float b1, float b2, float eps,
+                                                         const int* __restrict__ step, float grad_scale) {
+  int t = 0;
+  while (t + 1 < a.count && blockIdx.x >= a.first_block[t + 1]) ++t;      // wave-uniform scan of <= 64 entries
+  const unsigned base = (blockIdx.x - a.first_block[t]) * DSR_ADAM_CHUNK;
+  const unsigned n = a.n[t];
+  float* __restrict__ p = a.p[t];
+  const float* __restrict__ g = a.g[t];
+  float* __restrict__ m = a.m[t];
+  float* __restrict__ v = a.v[t];
+  const int ts = *step;
+  const float bc1 = 1.f - powf(b1, (float)ts);
+  const float rbc2 = 1.f / sqrtf(1.f - powf(b2, (float)ts));
+  const float step_size = lr / bc1;
+#pragma unroll 4
+  for (unsigned i = base + threadIdx.x; i < base + DSR_ADAM_CHUNK && i < n; i += 256) {
+    const float gk = g[i] * grad_scale;
+    const float mk = b1 * m[i] + (1.f - b1) * gk;
+    const float vk = b2 * v[i] + (1.f - b2) * gk * gk;
+    m[i] = mk;
+    v[i] = vk;
+    p[i] -= step_size * (mk / (sqrtf(vk) * rbc2 + eps));
+  }
+}
+extern "C" int dsr_pw_adam_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                 const size_t* n, float lr, float b1, float b2, float eps, const int* step,
+                                 float grad_scale, hipStream_t st) {
+  if (count < 0 || (count && (!p || !g || !m || !v || !n))) return dsr_fail(DSR_E_ARG, "adam_multi: null table");
+  for (int i0 = 0; i0 < count; i0 += DSR_ADAM_GROUP) {
+    AdamGroup a;
+    a.count = count - i0 < DSR_ADAM_GROUP ? count - i0 : DSR_ADAM_GROUP;
+    unsigned blocks = 0;
+    for (int j = 0; j < a.count; ++j) {
+      if (n[i0 + j] > 0xFFFFFFFFull - DSR_ADAM_CHUNK) return dsr_fail(DSR_E_UNSUPPORTED, "adam_multi: tensor too large");
+      a.p[j] = p[i0 + j];
+      a.g[j] = g[i0 + j];
+      a.m[j] = m[i0 + j];
+      a.v[j] = v[i0 + j];
+      a.n[j] = (unsigned)n[i0 + j];
+      a.first_block[j] = blocks;
+      blocks += (unsigned)((n[i0 + j] + DSR_ADAM_CHUNK - 1) / DSR_ADAM_CHUNK);
+    }
+    a.first_block[a.count] = blocks;
+    if (blocks) hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, st, a, lr, b1, b2, eps, step, grad_scale);
+  }
+  return dsr_launch_status("dsr_pw_adam_multi");
+}
 extern "C" int dsr_pw_incr(int* step, hipStream_t st) {
   hipLaunchKernelGGL(incr_kernel, dim3(1), dim3(1), 0, st, step);
   return dsr_launch_status("dsr_pw_incr");

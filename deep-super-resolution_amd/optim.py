@@ -10,6 +10,8 @@ from .functional import _ptr, _stream, bump, check, mark_shadow_current, shadow_
 
 
 class FusedAdam:
+    MULTI_MAX = 1 << 20      # tensors up to this many elements go through the multi-tensor launch
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
         self.params = [p for p in params]
         if not self.params:
@@ -32,15 +34,26 @@ class FusedAdam:
         lib = _lib.lib()
         st = _stream()
         check(lib.dsr_pw_incr(_ptr(self.step_t), st))
+        small, keep = [], []
         for p, m, v in zip(self.params, self.m, self.v):
             if p.grad is None:
                 continue
             g = p.grad
             if g.dtype != torch.float32 or not g.is_contiguous():
                 g = g.float().contiguous()
+                keep.append(g)
             sh = shadow_for_update(p)        # bf16 image kept by DenseHead for this matrix (or None)
-            check(lib.dsr_pw_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), self.lr, self.betas[0], self.betas[1],
-                                  self.eps, _ptr(self.step_t), self.grad_scale, _ptr(sh), st))
+            if sh is None and p.numel() <= self.MULTI_MAX and p.is_contiguous():
+                small.append((p, g, m, v))
+            else:
+                check(lib.dsr_pw_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), self.lr, self.betas[0],
+                                      self.betas[1], self.eps, _ptr(self.step_t), self.grad_scale, _ptr(sh), st))
+                if sh is not None:
+                    mark_shadow_current(p)
             bump(p)
-            if sh is not None:
-                mark_shadow_current(p)
+        if small:                            # every small tensor in one launch per 64 (dsr_pw_adam_multi)
+            k = len(small)
+            arr = [(C.c_void_p * k)(*[t[i].data_ptr() for t in small]) for i in range(4)]
+            ns = (C.c_size_t * k)(*[t[0].numel() for t in small])
+            check(lib.dsr_pw_adam_multi(k, arr[0], arr[1], arr[2], arr[3], ns, self.lr, self.betas[0], self.betas[1],
+                                        self.eps, _ptr(self.step_t), self.grad_scale, st))

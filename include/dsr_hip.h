@@ -137,6 +137,11 @@ int dsr_pw_bce_const(const float* p, int n, float target, float* loss, float* gr
  * shadow_bf16 (nullable): also write the bf16 image of the updated parameter (same layout) */
 int dsr_pw_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                 const int* step, float grad_scale, void* shadow_bf16, dsr_stream_t s);
+/* the same update for `count` tensors in as few launches as possible (64 tensors per launch); the four pointer
+ * arrays and n[] are HOST arrays of device pointers / element counts, read before the call returns */
+int dsr_pw_adam_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
+                      const size_t* n, float lr, float b1, float b2, float eps, const int* step, float grad_scale,
+                      dsr_stream_t s);
 int dsr_pw_incr(int* step, dsr_stream_t s);
 
 /* ------------------------------------------------------------------ discriminator dense head (linear.hip)

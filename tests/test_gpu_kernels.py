@@ -78,6 +78,7 @@ CONV_CASES = [
     ("trunk3x3_tail", 1, 64, 64, 7, 9, 3, 1, 1, 0, "leaky"),
     ("head9x9", 2, 3, 64, 16, 16, 9, 1, 4, 0, "prelu"),
     ("d_first", 2, 3, 64, 16, 24, 3, 1, 1, 0, "leaky"),
+    ("d_first_ragged", 3, 3, 64, 37, 70, 3, 1, 1, 0, "leaky"),
     ("d_s2_64", 2, 64, 64, 16, 16, 3, 2, 1, 0, "none"),
     ("d_s2_odd", 1, 64, 128, 15, 17, 3, 2, 1, 0, "none"),
     ("d_128_256", 1, 128, 256, 8, 8, 3, 1, 1, 0, "relu"),
@@ -318,3 +319,28 @@ def test_losses_and_adam(dev):
         og.step()
     torch.cuda.synchronize()
     assert rel_err(wg.detach().cpu(), wr.detach()) < 1e-6
+
+
+def test_adam_multi_tensor_matches_per_tensor(dev):
+    """dsr_pw_adam_multi (one launch per 64 tensors) matches dsr_pw_adam to the last ulp or two, for 150 ragged tensors and
+    against torch.optim.Adam (train_GAN.py:35-36)."""
+    optim = P("optim")
+    shapes = [(1 + (7 * i) % 33, 1 + (5 * i) % 19) for i in range(149)] + [(9000,)]
+    w0 = [filler.tensor(f"am:w{i}", s) for i, s in enumerate(shapes)]
+    a = [w.to(dev).requires_grad_(True) for w in w0]
+    b = [w.to(dev).requires_grad_(True) for w in w0]
+    r = [w.clone().requires_grad_(True) for w in w0]
+    oa, ob = optim.FusedAdam(a, lr=3e-3), optim.FusedAdam(b, lr=3e-3)
+    ob.MULTI_MAX = 0                      # per-tensor launches
+    oref = torch.optim.Adam(r, lr=3e-3)
+    for it in range(3):
+        for i, s in enumerate(shapes):
+            g = filler.tensor(f"am:g{it}:{i}", s)
+            a[i].grad, b[i].grad, r[i].grad = g.to(dev), g.to(dev), g.clone()
+        oa.step()
+        ob.step()
+        oref.step()
+    torch.cuda.synchronize()
+    for i in range(len(shapes)):
+        assert rel_err(a[i].detach().cpu(), b[i].detach().cpu()) < 1e-6, i      # FMA contraction may differ by an ulp
+        assert rel_err(a[i].detach().cpu(), r[i].detach()) < 1e-6, i
