@@ -15,11 +15,14 @@
 //    accumulators, one partial row per M-tile: deterministic, no atomics), staged through LDS so that
 //    global stores are 16-byte NHWC vectors; optional PixelShuffle(2) store
 //    (out[n,2h+i,2w+j,c] = y[n,h,w,4c+2i+j], generator.py:32,38) or fp32 NCHW store for the last layer.
+#include <stdlib.h>
+
 #include "dsr_common.h"
 #include "dsr_kernels.h"
 
-template <int DT, int BM, int BN, int WGM, int WGN, bool FAST>
+template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA>
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 2) void conv_gemm_kernel(const ConvGemmArgs a) {
+  static_assert(!DMA || FAST, "the LDS-DMA loader exists for the fast path only");
   constexpr int NW = WGM * WGN;                 // 4 or 8 waves; two blocks per CU either way
   constexpr int NT = 64 * NW;
   constexpr int RPP = NT / 8;                   // tile rows covered by one pass of the loader (8 lanes per row)
@@ -80,15 +83,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 2) void conv_gemm_ker
   // fast path: zero padding and Cin a multiple of 64 -> the 8 units of a K-step share one tap (wave-uniform
   // decode) and a row's offset is (precomputed row base) + (per-step tap offset).
   // (FAST is a template parameter: the generic path's per-row state would otherwise cost ~20 VGPRs here)
+  // DMA loader: the LDS image of one wave-instruction is lane-linear (row rb, 16-byte slot j), so the XOR swizzle
+  // goes on the SOURCE side: slot j of row r holds channel chunk j ^ (r & 7).
+  const int jc = DMA ? (j ^ (rb & 7)) : j;
   int a_base[RA], b_base[RB];
 #pragma unroll
-  for (int i = 0; i < RA; ++i) a_base[i] = ((a_nb[i] + a_iy0[i] * a.IW + a_ix0[i]) * a.CinP + j * 8) * 2;   // bytes
+  for (int i = 0; i < RA; ++i) a_base[i] = ((a_nb[i] + a_iy0[i] * a.IW + a_ix0[i]) * a.CinP + jc * 8) * 2;   // bytes
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
     // weight rows beyond NB only feed output columns that are never stored: clamp the row instead of predicating
     const int row = rb + RPP * i;
     const int co = (n0 + row) < a.NB ? (n0 + row) : a.NB - 1;
-    b_base[i] = (co * a.CinP + j * 8) * 2;
+    b_base[i] = (co * a.CinP + jc * 8) * 2;
   }
 
   const int cu8 = a.CU >> 3;
@@ -140,6 +146,30 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 2) void conv_gemm_ker
     }
     }
   };
+  // LDS-DMA variant of load_step: `buffer_load_dwordx4 ... lds` writes 64 lanes x 16 B = 8 tile rows straight into
+  // the stage (an out-of-range offset writes zeros), so the operand tiles never pass through VGPRs.
+  [[maybe_unused]] auto dma_step = [&](int s, int stage) {
+    const int t = fd_div(a.fd_cu8, s);
+    const int cbase = (s - t * cu8) * 64;
+    const int tp = sTaps[t];
+    const int dy = (int)(signed char)(tp & 0xff);
+    const int dx = (int)(signed char)((tp >> 8) & 0xff);
+    const int widx = (tp >> 16) & 0xffff;
+    const int toff = ((dy * a.IW + dx) * a.CinP + cbase) * 2;
+    const int woff = (widx * a.NB * a.CinP + cbase) * 2;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const bool inb = (unsigned)(a_iy0[i] + dy) < (unsigned)a.IH && (unsigned)(a_ix0[i] + dx) < (unsigned)a.IW;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(sA + stage * A_STAGE + (wave * 8 + RPP * i) * 128), 16,
+                                               inb ? (unsigned)(a_base[i] + toff) : OOB, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+      if (RPP * i < BN)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + stage * B_STAGE + (wave * 8 + RPP * i) * 128), 16,
+                                                 (unsigned)(b_base[i] + woff), 0, 0, 0);
+  };
   int st_off[RA > RB ? RA : RB];
 #pragma unroll
   for (int i = 0; i < (RA > RB ? RA : RB); ++i) {
@@ -165,13 +195,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 2) void conv_gemm_ker
   // other.  An iteration = {write set(s+1) -> LDS[(s+1)&1]; issue loads of s+3 into that set; 32 MFMAs on
   // LDS[s&1]; barrier}: every global load gets two full iterations of MFMA work to land.
   const int ks = a.ksteps;
-  load_step(0, ra0, rb0);
-  store_step(0, ra0, rb0);
-  if constexpr (BN <= 128) {
-    if (ks > 1) load_step(1, ra1, rb1);
-    if (ks > 2) load_step(2, ra0, rb0);
+  if constexpr (!DMA) {
+    load_step(0, ra0, rb0);
+    store_step(0, ra0, rb0);
+    if constexpr (BN <= 128) {
+      if (ks > 1) load_step(1, ra1, rb1);
+      if (ks > 2) load_step(2, ra0, rb0);
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   const int sw = r16 & 7;
   auto compute = [&](int cur) {
@@ -192,7 +224,36 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 2) void conv_gemm_ker
         for (int k = 0; k < TN; ++k) acc[i][k] = mfma16<DT>(fa[i], fb[k], acc[i][k]);
     }
   };
-  if constexpr (BN <= 128) {
+  if constexpr (DMA) {
+    // One barrier per K-step: {wait for my own DMA of step s; barrier: step s has landed for every wave and every
+    // wave is done reading the other stage; start the DMA of step s+1 into that stage; 32 MFMAs on step s}.
+    auto compute_flat = [&](int cur) {
+      const unsigned char* pa = sA + cur * A_STAGE + (wm * WM + r16) * 128;
+      const unsigned char* pb = sB + cur * B_STAGE + (wn * WN + r16) * 128;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int slot = ((4 * kk + g) ^ sw) << 4;
+        U4 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const U4*>(pa + i * 16 * 128 + slot);
+#pragma unroll
+        for (int k = 0; k < TN; ++k) fb[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int k = 0; k < TN; ++k) acc[i][k] = mfma16<DT>(fa[i], fb[k], acc[i][k]);
+      }
+    };
+    dma_step(0, 0);
+    for (int s = 0; s < ks; ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + 1 < ks) dma_step(s + 1, (s + 1) & 1);
+      compute_flat(s & 1);
+    }
+    __syncthreads();   // the epilogue reuses the stages as its C tile
+  } else if constexpr (BN <= 128) {
     for (int s = 0; s < ks; s += 2) {
       // even step: LDS[0] = s, set1 = s+1, set0 = s+2 (in flight)
       if (s + 1 < ks) store_step(1, ra1, rb1);
@@ -365,10 +426,20 @@ static void launch_one(const ConvGemmArgs& a, hipStream_t st) {
   b.tiles_n = (a.NB + BN - 1) / BN;
   dim3 grid(b.tiles_m * b.tiles_n), block(64 * WGM * WGN);
   const bool fast = a.pad_mode == DSR_PAD_ZERO && (a.CU & 7) == 0 && a.ntaps > 0;
+  if constexpr (BN >= 64) {
+    static const bool use_dma = [] {
+      const char* e = getenv("DSR_CONV_DMA");      // tuning switch (default on): 0 = register-staged loader
+      return !(e && e[0] == '0');
+    }();
+    if (fast && use_dma) {
+      hipLaunchKernelGGL((conv_gemm_kernel<DT, BM, BN, WGM, WGN, true, true>), grid, block, 0, st, b);
+      return;
+    }
+  }
   if (fast)
-    hipLaunchKernelGGL((conv_gemm_kernel<DT, BM, BN, WGM, WGN, true>), grid, block, 0, st, b);
+    hipLaunchKernelGGL((conv_gemm_kernel<DT, BM, BN, WGM, WGN, true, false>), grid, block, 0, st, b);
   else
-    hipLaunchKernelGGL((conv_gemm_kernel<DT, BM, BN, WGM, WGN, false>), grid, block, 0, st, b);
+    hipLaunchKernelGGL((conv_gemm_kernel<DT, BM, BN, WGM, WGN, false, false>), grid, block, 0, st, b);
 }
 
 int dsr_conv_gemm_bm(int /*NB*/) { return 128; }
