@@ -6,8 +6,7 @@
 //     (9 taps x 2 k-halves x 2 n-tiles = 36 fragments = 144 VGPRs) for the whole launch,
 //   * the 2-row x 32-column pixel tile's input HALO (4 x 34 pixels) is staged once in LDS and every tap is an
 //     address offset into it (A fragments: one conflict-free ds_read_b128 per 2 MFMAs),
-//   * the NEXT tile's halo travels HBM -> registers under the current tile's 72 MFMAs per wave,
-//     (2-row tiles: 144 weight + 16 accumulator + 16 fragment + 20 prefetch registers fit two waves per SIMD)
+//   * the NEXT tile's halo travels HBM -> LDS by LDS-DMA (no VGPRs) under the current tile's 72 MFMAs per wave,
 // so the MFMA phase touches LDS only.  Same epilogue contract as conv_gemm (bias, activation, BatchNorm
 // sum / sum-of-squares rows -- one row per spatial TILE here --, 16-byte NHWC stores).  dgrad = the same kernel on the
 // [tap][ci][co] weight image with mirrored tap offsets.
@@ -21,9 +20,12 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   constexpr int HRW = TR + 2;                  // halo rows
   constexpr int X_BYTES = HRW * HC * 128;      // 20,480
   constexpr int C_STRIDE = 64 * 2 + 16;
-  __shared__ __attribute__((aligned(16))) unsigned char sX[X_BYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char sC[TR * 32 * C_STRIDE];
-  __shared__ float sStat[2][2][64];
+  // one LDS object (a second one beside an LDS-DMA target makes hipcc drain the DMA before every LDS read):
+  // two halo stages | C tile | statistics
+  constexpr int C_BYTES = TR * 32 * C_STRIDE;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X_BYTES + C_BYTES + 2 * 2 * 64 * 4];
+  unsigned char* sC = smem + 2 * X_BYTES;
+  float (*sStat)[2][64] = reinterpret_cast<float (*)[2][64]>(smem + 2 * X_BYTES + C_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
   const int wp = wave >> 1, wc = wave & 1;     // tile row, channel half (32 co)
@@ -48,12 +50,17 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) lds_off[tx][kk] = (tx + r16) * 128 + (((4 * kk + g) ^ ((tx + r16) & 7)) << 4);
 
-  const int c = tid & 7, pb = tid >> 3;        // loader: chunk c of halo pixels pb + 32u
+  // loader: LDS-DMA (buffer_load ... lds): wave-instruction u of wave w fills halo slots 32u + 8w .. +7 (8 pixels x
+  // 128 B, lane-linear), slot position (lane & 7) of pixel q holding channel chunk (lane & 7) ^ (q & 7); an
+  // out-of-range offset writes zeros (image border, pad columns 34..39).  The tile never passes through VGPRs.
+  const int c = (tid & 7) ^ ((tid >> 3) & 7), pb = tid >> 3;
   constexpr int NV = (HRW * HC + 31) / 32;     // 5
   const int hr0 = pb / HC, hc0 = pb - hr0 * HC;
   const int per_img = a.tiles_y * a.tiles_x;
-  U4 v[NV];
-  auto fetch = [&](int t) {
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto fetch = [&](int t, int buf) {
     const int n = t / per_img;
     const int rem = t - n * per_img;
     const int oy0 = (rem / a.tiles_x) * TR - 1, ox0 = (rem % a.tiles_x) * 32 - 1;
@@ -62,20 +69,8 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     for (int u = 0; u < NV; ++u) {
       const int iy = oy0 + hr, ix = ox0 + hc;
       const bool ok = hr < HRW && hc < 34 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      v[u] = load16_or_zero(X, ((size_t)(n * a.H + iy) * a.W + ix) * 64 + c * 8, ok);
-      hc += 32;
-      if (hc >= HC) {
-        hc -= HC;
-        ++hr;
-      }
-    }
-  };
-  auto stash = [&]() {
-    int hr = hr0, hc = hc0;
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int q = hr * HC + hc;
-      if (hr < HRW) *reinterpret_cast<U4*>(sX + q * 128 + ((c ^ (q & 7)) << 4)) = v[u];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(smem + buf * X_BYTES + (32 * u + 8 * wave) * 128), 16,
+                                               ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * 64 + c * 8) * 2) : OOB, 0, 0, 0);
       hc += 32;
       if (hc >= HC) {
         hc -= HC;
@@ -92,12 +87,15 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
 
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tstep = gridDim.x;
-  if (t < a.ntiles) fetch(t);
-  for (; t < a.ntiles; t += tstep) {
-    __syncthreads();                           // previous tile: fragment reads and C-tile reads are done
-    stash();
-    __syncthreads();
-    if (t + tstep < a.ntiles) fetch(t + tstep);
+  if (t < a.ntiles) fetch(t, 0);
+  int buf = 0;
+  for (; t < a.ntiles; t += tstep, buf ^= 1) {
+    // my DMA of this tile is done; after the barrier everyone's is, and every wave is past the previous tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + tstep < a.ntiles) fetch(t + tstep, buf ^ 1);
+    const unsigned char* sX = smem + buf * X_BYTES;
 
     f32x4 acc[2][2];                           // m-tile = half hx of the wave's row ; n-tile nt
 #pragma unroll
@@ -167,7 +165,10 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
       epilogue([slope](float x) { return x >= 0.f ? x : x * slope; });
     else
       epilogue([&](float x) { return act_apply(a.act, x, slope); });
-    __syncthreads();
+    // raw barrier: a __syncthreads() here would also drain the next tile's DMA
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     if (do_stats && tid < 128) {
       const int which = tid >> 6, col = tid & 63;
       a.stats[((size_t)t * 2 + which) * 64 + col] = sStat[0][which][col] + sStat[1][which][col];
@@ -191,6 +192,7 @@ void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st) {
   a.tiles_y = (a.H + 1) / 2;
   a.tiles_x = (a.W + 31) / 32;
   a.ntiles = N * a.tiles_y * a.tiles_x;
+  a.x_bytes = (unsigned)((size_t)N * a.H * a.W * 128);
   dim3 grid(a.ntiles < 512 ? a.ntiles : 512), block(256);     // persistent, 2 resident blocks per CU
   if (dtype == DSR_DTYPE_BF16)
     hipLaunchKernelGGL((conv_c64_kernel<DSR_DTYPE_BF16>), grid, block, 0, st, a);
