@@ -423,6 +423,8 @@ static int tile_plan(const dsr_conv_desc* d, WgradTileArgs& t, bool* taps_kernel
   t.CoutP = r8(d->Cout);
   t.pad = d->pad;
   t.pad_mode = d->pad_mode;
+  t.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * r8(d->Cin) * 2);       // check_desc keeps both below 2 GiB
+  t.dy_bytes = (unsigned)((size_t)d->N * OH * OW * r8(d->Cout) * 2);
   return ych;
 }
 

@@ -20,9 +20,19 @@
 #include "dsr_common.h"
 #include "dsr_kernels.h"
 
-template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA>
-__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 2) void conv_gemm_kernel(const ConvGemmArgs a) {
+template <int BM, int BN, int WGM, int NSTAGE>
+struct ConvGemmLds {
+  static constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128;
+  static constexpr int MAIN = NSTAGE * (A_STAGE + B_STAGE);
+  static constexpr int C = BM * (BN * 2 + 16);
+  static constexpr int TILE = MAIN > C ? MAIN : C;
+  static constexpr int TOTAL = TILE + WGM * 2 * BN * 4 + DSR_MAX_TAPS * 4;
+};
+
+template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA, int NSTAGE>
+__global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) void conv_gemm_kernel(const ConvGemmArgs a) {
   static_assert(!DMA || FAST, "the LDS-DMA loader exists for the fast path only");
+  static_assert(NSTAGE == 2 || (NSTAGE == 3 && DMA), "three stages: DMA ring only");
   constexpr int NW = WGM * WGN;                 // 4 or 8 waves; two blocks per CU either way
   constexpr int NT = 64 * NW;
   constexpr int RPP = NT / 8;                   // tile rows covered by one pass of the loader (8 lanes per row)
@@ -33,13 +43,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 2) void conv_gemm_ker
   constexpr int RA = BM / RPP;
   constexpr int RB = (BN + RPP - 1) / RPP;
   constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128;
-  constexpr int LDS_MAIN = 2 * (A_STAGE + B_STAGE);
+  constexpr int LDS_MAIN = NSTAGE * (A_STAGE + B_STAGE);
   constexpr int C_STRIDE = BN * 2 + 16;
   constexpr int LDS_C = BM * C_STRIDE;
   constexpr int LDS_BYTES = LDS_MAIN > LDS_C ? LDS_MAIN : LDS_C;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + WGM * 2 * BN * 4 + DSR_MAX_TAPS * 4];
+  // one dynamic LDS object (size ConvGemmLds<...>::TOTAL, passed at launch): stages | statistics | tap table
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert(LDS_BYTES == ConvGemmLds<BM, BN, WGM, NSTAGE>::TILE, "LDS layout");
   unsigned char* sA = smem;
-  unsigned char* sB = smem + 2 * A_STAGE;
+  unsigned char* sB = smem + NSTAGE * A_STAGE;
   float* sStat = reinterpret_cast<float*>(smem + LDS_BYTES);
   int* sTaps = reinterpret_cast<int*>(smem + LDS_BYTES + WGM * 2 * BN * 4);
 
@@ -244,13 +256,35 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 2) void conv_gemm_ker
           for (int k = 0; k < TN; ++k) acc[i][k] = mfma16<DT>(fa[i], fb[k], acc[i][k]);
       }
     };
-    dma_step(0, 0);
-    for (int s = 0; s < ks; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (s + 1 < ks) dma_step(s + 1, (s + 1) & 1);
-      compute_flat(s & 1);
+    if constexpr (NSTAGE == 2) {
+      dma_step(0, 0);
+      for (int s = 0; s < ks; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 1 < ks) dma_step(s + 1, (s + 1) & 1);
+        compute_flat(s & 1);
+      }
+    } else {
+      // three-stage ring, one resident block per CU: the DMA of step s+2 is issued before the MFMAs of step s, so a
+      // tile has two full compute phases to land.  At the top of step s the groups of steps s and s+1 are in
+      // flight; vmcnt(NDMA) retires the older one only (a wave issues exactly NDMA DMA instructions per step).
+      constexpr int NDMA = RA + (BN + RPP - 1) / RPP;
+      dma_step(0, 0);
+      if (ks > 1) dma_step(1, 1);
+      int cur = 0, nxt2 = 2;
+      for (int s = 0; s < ks; ++s) {
+        if (s + 1 < ks)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 2 < ks) dma_step(s + 2, nxt2);
+        compute_flat(cur);
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+      }
     }
     __syncthreads();   // the epilogue reuses the stages as its C tile
   } else if constexpr (BN <= 128) {
@@ -363,10 +397,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 2) void conv_gemm_ker
       int which = c / BN, ct = c % BN;
       int col = n0 + ct;
       if (col < a.cout) {
-        float s = 0.f;
+        // one statistics row per 128 tile rows (dsr_conv_stats_rows), whatever BM is
+        constexpr int WPR = 128 / WM;                 // wave rows per statistics row
 #pragma unroll
-        for (int w = 0; w < WGM; ++w) s += sStat[(w * 2 + which) * BN + ct];
-        a.stats[((size_t)tile_m * 2 + which) * a.stats_stride + col] = s;
+        for (int h = 0; h < BM / 128; ++h) {
+          float s = 0.f;
+#pragma unroll
+          for (int w = 0; w < WPR; ++w) s += sStat[((h * WPR + w) * 2 + which) * BN + ct];
+          if (BM == 128 || m0 + 128 * h < a.M)
+            a.stats[((size_t)(tile_m * (BM / 128) + h) * 2 + which) * a.stats_stride + col] = s;
+        }
       }
     }
   }
@@ -419,36 +459,65 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 2) void conv_gemm_ker
   }
 }
 
-template <int DT, int BM, int BN, int WGM, int WGN>
+template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA, int NSTAGE>
+static void launch_variant(dim3 grid, const ConvGemmArgs& b, hipStream_t st) {
+  constexpr int LDS = ConvGemmLds<BM, BN, WGM, NSTAGE>::TOTAL;
+  auto* fn = conv_gemm_kernel<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE>;
+  if constexpr (LDS > 64 * 1024) {   // more than 64 KB of dynamic LDS needs the opt-in, once per kernel (not a stream op)
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(64 * WGM * WGN), LDS, st, b);
+}
+
+static bool env_on(const char* name) {   // tuning switches, default on ("0" turns one off)
+  const char* e = getenv(name);
+  return !(e && e[0] == '0');
+}
+
+template <int DT, int BM, int BN, int WGM, int WGN, int NSTAGE = 2>
 static void launch_one(const ConvGemmArgs& a, hipStream_t st) {
   ConvGemmArgs b = a;
   b.tiles_m = (a.M + BM - 1) / BM;
   b.tiles_n = (a.NB + BN - 1) / BN;
-  dim3 grid(b.tiles_m * b.tiles_n), block(64 * WGM * WGN);
+  dim3 grid(b.tiles_m * b.tiles_n);
   const bool fast = a.pad_mode == DSR_PAD_ZERO && (a.CU & 7) == 0 && a.ntaps > 0;
-  if constexpr (BN >= 64) {
-    static const bool use_dma = [] {
-      const char* e = getenv("DSR_CONV_DMA");      // tuning switch (default on): 0 = register-staged loader
-      return !(e && e[0] == '0');
-    }();
-    if (fast && use_dma) {
-      hipLaunchKernelGGL((conv_gemm_kernel<DT, BM, BN, WGM, WGN, true, true>), grid, block, 0, st, b);
-      return;
+  if constexpr (NSTAGE == 3) {
+    launch_variant<DT, BM, BN, WGM, WGN, true, true, 3>(grid, b, st);
+    return;
+  } else {
+    if constexpr (BN >= 64) {
+      static const bool use_dma = env_on("DSR_CONV_DMA");      // 0 = register-staged loader
+      if (fast && use_dma) {
+        launch_variant<DT, BM, BN, WGM, WGN, true, true, 2>(grid, b, st);
+        return;
+      }
     }
+    if (fast)
+      launch_variant<DT, BM, BN, WGM, WGN, true, false, 2>(grid, b, st);
+    else
+      launch_variant<DT, BM, BN, WGM, WGN, false, false, 2>(grid, b, st);
   }
-  if (fast)
-    hipLaunchKernelGGL((conv_gemm_kernel<DT, BM, BN, WGM, WGN, true, false>), grid, block, 0, st, b);
-  else
-    hipLaunchKernelGGL((conv_gemm_kernel<DT, BM, BN, WGM, WGN, false, false>), grid, block, 0, st, b);
 }
 
 int dsr_conv_gemm_bm(int /*NB*/) { return 128; }
 
 template <int DT>
 static void dispatch_dt(const ConvGemmArgs& a, hipStream_t st) {
-  if (a.NB > 64)
-    launch_one<DT, 128, 128, 2, 2>(a, st);      // (8 waves of 64x32 were tried: LDS-bound, 35 % slower)
-  else if (a.NB > 16)
+  if (a.NB > 64) {
+    // big problems: 256x128 tiles, 8 waves, three-stage DMA ring, one block per CU (needs >= 2 blocks per CU of work)
+    // measured: 5-12 % SLOWER than two resident 128x128 blocks on every config-3 layer, so it is off unless asked for
+    static const bool use_big = [] { const char* e = getenv("DSR_CONV_BIG"); return e && e[0] == '1'; }();
+    const bool fast = a.pad_mode == DSR_PAD_ZERO && (a.CU & 7) == 0 && a.ntaps > 0;
+    const long long big_tiles = (long long)((a.M + 255) / 256) * ((a.NB + 127) / 128);
+    if (use_big && fast && big_tiles >= 512)
+      launch_one<DT, 256, 128, 4, 2, 3>(a, st);
+    else
+      launch_one<DT, 128, 128, 2, 2>(a, st);      // (8 waves of 64x32 were tried: LDS-bound, 35 % slower)
+  } else if (a.NB > 16)
     launch_one<DT, 128, 64, 2, 2>(a, st);
   else
     launch_one<DT, 128, 16, 4, 1>(a, st);

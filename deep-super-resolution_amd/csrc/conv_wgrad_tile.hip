@@ -123,11 +123,271 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(const WgradTile
         }
 }
 
+// ------------------------------------------------------------------ 3x3 / stride 1 with an LDS-DMA operand pipeline
+// Same decomposition as above (block = one 64 co x 64 ci pair, pixels are the contraction index, all 9 taps from one
+// staged halo), rebuilt around `buffer_load ... lds`:
+//   * tiles are 2 output rows x 32 columns; the dY tile (8 KB) and the X halo (4 x 40 pixels, 20 KB) of the NEXT
+//     tile stream HBM -> LDS under the 72 MFMAs per wave of the current one (two stages, one barrier per tile, no
+//     VGPR staging, no ds_write pass);
+//   * the halo row pitch is 40 pixels (a multiple of 8), so the XOR swizzle key of a fragment read,
+//     (pixel index & 7), depends on the lane and the tap COLUMN only: every read address is one per-lane register
+//     plus an immediate -- the 9-tap loop carries no address arithmetic (the older kernel spent ~6 VALU
+//     instructions per MFMA on it).
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradTileArgs a) {
+  constexpr int R = 2, HC = 40, HR = R + 2;
+  constexpr int XB = HR * HC * 128, YB = R * 32 * 128, STAGE = XB + YB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
+  const int pair = blockIdx.x;
+  const int co0 = (pair / a.tiles_ci) * 64, ci0 = (pair % a.tiles_ci) * 64;
+
+  f32x4 acc[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment read offsets (bytes inside a stage): rows lp = 4g + q4 (and lp + 16 at +2048)
+  const int lp = 4 * g + q4;
+  int offA[2], offB[3][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = wr * 32 + i * 16 + cc;
+    offA[i] = XB + lp * 128 + (((ch >> 3) ^ (lp & 7)) << 4) + (ch & 7) * 2;
+  }
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ch = wc * 32 + j * 16 + cc;
+      offB[kw][j] = lp * 128 + (((ch >> 3) ^ ((kw + lp) & 7)) << 4) + (ch & 7) * 2;
+    }
+
+  // ---- DMA loader: slot position (lane & 7) of pixel slot q = 32u + 8*wave + (lane >> 3) holds chunk (lane&7)^(q&7)
+  const int chunk = (tid & 7) ^ ((tid >> 3) & 7), pb = tid >> 3;
+  const bool yc_ok = (co0 + chunk * 8) < a.CoutP, xc_ok = (ci0 + chunk * 8) < a.CinP;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int per_img = a.tiles_y * a.tiles_x;
+  auto dma = [&](int t, int buf) {
+    const int n = t / per_img;
+    const int rem = t - n * per_img;
+    const int ty = rem / a.tiles_x;
+    const int oy0 = ty * R, ox0 = (rem - ty * a.tiles_x) * 32;
+    unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int u = 0; u < (HR * HC) / 32; ++u) {      // 5 wave-instructions per wave: the X halo
+      const int q = pb + 32 * u;
+      const int hr = q / HC, hc = q - hr * HC;
+      bool ok = xc_ok && hc < 34;
+      const int iy = pad_index(oy0 + hr - a.pad, a.IH, a.pad_mode, ok);
+      const int ix = pad_index(ox0 + hc - a.pad, a.IW, a.pad_mode, ok);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(st + (32 * u + 8 * wave) * 128), 16,
+                                               ok ? (unsigned)((((n * a.IH + iy) * a.IW + ix) * a.CinP + ci0 + chunk * 8) * 2) : OOB,
+                                               0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < (R * 32) / 32; ++u) {       // 2 per wave: the dY tile
+      const int p = pb + 32 * u;
+      const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
+      const bool ok = yc_ok && oy < a.OH && ox < a.OW;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr)(st + XB + (32 * u + 8 * wave) * 128), 16,
+                                               ok ? (unsigned)((((n * a.OH + oy) * a.OW + ox) * a.CoutP + co0 + chunk * 8) * 2) : OOB,
+                                               0, 0, 0);
+    }
+  };
+
+  int t = blockIdx.y * a.tiles_per_block;
+  int t_end = t + a.tiles_per_block;
+  if (t_end > a.ntiles) t_end = a.ntiles;
+  if (t < t_end) dma(t, 0);
+  int buf = 0;
+  for (; t < t_end; ++t, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // this tile has landed; nobody still reads the other stage
+    asm volatile("" ::: "memory");
+    if (t + 1 < t_end) dma(t + 1, buf ^ 1);
+    const unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      U4 fa[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const s16x4 lo = tr_read(st + offA[i] + r * 32 * 128);
+        const s16x4 hi = tr_read(st + offA[i] + r * 32 * 128 + 2048);
+        fa[i] = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          U4 fb[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const s16x4 lo = tr_read(st + offB[kw][j] + ((r + kh) * HC + kw) * 128);
+            const s16x4 hi = tr_read(st + offB[kw][j] + ((r + kh) * HC + kw) * 128 + 2048);
+            fb[j] = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[kh * 3 + kw][i][j] = mfma16<DT>(fa[i], fb[j], acc[kh * 3 + kw][i][j]);
+        }
+    }
+  }
+
+  float* P = a.partial + (size_t)blockIdx.y * 9 * a.CoutP * a.CinP;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + wr * 32 + i * 16 + 4 * g + r, ci = ci0 + wc * 32 + j * 16 + l16;
+          if (co < a.CoutP && ci < a.CinP) P[((size_t)tp * a.CoutP + co) * a.CinP + ci] = acc[tp][i][j][r];
+        }
+}
+
+// ------------------------------------------------------------------ 3x3 / stride 2, same LDS-DMA pipeline
+// Tiles are 1 output row x 32 columns; the halo is 3 rows x 65 pixels at a pitch of 80.  A fragment's pixel slots
+// are 2 apart (q = kh*80 + kw + 2*lp), so the swizzle key is taken from (q >> 1): with an 80-pixel pitch it reduces to
+// (lp + (kw >> 1)) & 7 -- per-lane, two variants -- and 16 consecutive fragment rows still spread over all 8 slots.
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTileArgs a) {
+  constexpr int HC = 80, HR = 3, NSLOT = HR * HC;
+  constexpr int XB = NSLOT * 128, YB = 32 * 128, STAGE = XB + YB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
+  const int pair = blockIdx.x;
+  const int co0 = (pair / a.tiles_ci) * 64, ci0 = (pair % a.tiles_ci) * 64;
+
+  f32x4 acc[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lp = 4 * g + q4;
+  int offA[2], offB[2][2];                 // offB[kw >> 1][j]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = wr * 32 + i * 16 + cc;
+    offA[i] = XB + lp * 128 + (((ch >> 3) ^ (lp & 7)) << 4) + (ch & 7) * 2;
+  }
+#pragma unroll
+  for (int v = 0; v < 2; ++v)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ch = wc * 32 + j * 16 + cc;
+      offB[v][j] = 2 * lp * 128 + (((ch >> 3) ^ ((lp + v) & 7)) << 4) + (ch & 7) * 2;
+    }
+
+  const int pb = tid >> 3;
+  const int xchunk = (tid & 7) ^ ((4 * wave + (lane >> 4)) & 7);     // key of slot q = 32u + 8*wave + (lane>>3): (q>>1)&7
+  const int ychunk = (tid & 7) ^ ((tid >> 3) & 7);
+  const bool yc_ok = (co0 + ychunk * 8) < a.CoutP, xc_ok = (ci0 + xchunk * 8) < a.CinP;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int per_img = a.tiles_y * a.tiles_x;
+  auto dma = [&](int t, int buf) {
+    const int n = t / per_img;
+    const int rem = t - n * per_img;
+    const int oy0 = rem / a.tiles_x, ox0 = (rem - oy0 * a.tiles_x) * 32;
+    unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int u = 0; u < (NSLOT + 31) / 32; ++u) {
+      if (32 * u + 8 * wave < NSLOT) {               // wave-uniform: the last pass only has slots for waves 0 and 1
+        const int q = pb + 32 * u;
+        const int hr = q / HC, hc = q - hr * HC;
+        bool ok = xc_ok && hc < 65;
+        const int iy = pad_index(oy0 * 2 + hr - a.pad, a.IH, a.pad_mode, ok);
+        const int ix = pad_index(ox0 * 2 + hc - a.pad, a.IW, a.pad_mode, ok);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(st + (32 * u + 8 * wave) * 128), 16,
+                                                 ok ? (unsigned)((((n * a.IH + iy) * a.IW + ix) * a.CinP + ci0 + xchunk * 8) * 2) : OOB,
+                                                 0, 0, 0);
+      }
+    }
+    {
+      const int ox = ox0 + pb;
+      const bool ok = yc_ok && ox < a.OW;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr)(st + XB + 8 * wave * 128), 16,
+                                               ok ? (unsigned)((((n * a.OH + oy0) * a.OW + ox) * a.CoutP + co0 + ychunk * 8) * 2) : OOB,
+                                               0, 0, 0);
+    }
+  };
+
+  int t = blockIdx.y * a.tiles_per_block;
+  int t_end = t + a.tiles_per_block;
+  if (t_end > a.ntiles) t_end = a.ntiles;
+  if (t < t_end) dma(t, 0);
+  int buf = 0;
+  for (; t < t_end; ++t, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 1 < t_end) dma(t + 1, buf ^ 1);
+    const unsigned char* st = smem + buf * STAGE;
+    U4 fa[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const s16x4 lo = tr_read(st + offA[i]);
+      const s16x4 hi = tr_read(st + offA[i] + 2048);
+      fa[i] = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        U4 fb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const s16x4 lo = tr_read(st + offB[kw >> 1][j] + (kh * HC + kw) * 128);
+          const s16x4 hi = tr_read(st + offB[kw >> 1][j] + (kh * HC + kw) * 128 + 32 * 128);
+          fb[j] = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[kh * 3 + kw][i][j] = mfma16<DT>(fa[i], fb[j], acc[kh * 3 + kw][i][j]);
+      }
+  }
+
+  float* P = a.partial + (size_t)blockIdx.y * 9 * a.CoutP * a.CinP;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + wr * 32 + i * 16 + 4 * g + r, ci = ci0 + wc * 32 + j * 16 + l16;
+          if (co < a.CoutP && ci < a.CinP) P[((size_t)tp * a.CoutP + co) * a.CinP + ci] = acc[tp][i][j][r];
+        }
+}
+
 int dsr_wgrad_tile_plan(int KH, int KW, int stride, int N, int OH, int OW, int CinP, int CoutP, WgradTileArgs* a) {
   const bool k3 = KH == 3 && KW == 3 && (stride == 1 || stride == 2);
   const bool k1 = KH == 1 && KW == 1 && stride == 1;
   if (!k3 && !k1) return 0;
-  const int R = stride == 1 ? 4 : 2;
+  const int R = k1 ? 4 : (stride == 1 ? 2 : 1);  // 3x3 runs on the LDS-DMA kernels: 2-row (stride 1) / 1-row (stride 2) tiles
   a->tiles_y = (OH + R - 1) / R;
   a->tiles_x = (OW + 31) / 32;
   a->ntiles = N * a->tiles_y * a->tiles_x;
@@ -144,9 +404,9 @@ int dsr_wgrad_tile_plan(int KH, int KW, int stride, int N, int OH, int OW, int C
 template <int DT>
 static void launch_dt(const WgradTileArgs& a, int KH, int stride, dim3 grid, hipStream_t st) {
   if (KH == 3 && stride == 1)
-    hipLaunchKernelGGL((conv_wgrad_tile_kernel<DT, 3, 3, 1>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<DT>), grid, dim3(256), 0, st, a);
   else if (KH == 3)
-    hipLaunchKernelGGL((conv_wgrad_tile_kernel<DT, 3, 3, 2>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_wgrad_dma_s2_kernel<DT>), grid, dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((conv_wgrad_tile_kernel<DT, 1, 1, 1>), grid, dim3(256), 0, st, a);
 }

@@ -78,6 +78,7 @@ struct WgradTileArgs {
   int pad, pad_mode;
   int tiles_co, tiles_ci;
   int tiles_y, tiles_x, ntiles, tiles_per_block;
+  unsigned x_bytes, dy_bytes;
 };
 // returns the number of partial slabs (ychunks) the launch will write, 0 if the shape is not handled
 int dsr_wgrad_tile_plan(int KH, int KW, int stride, int N, int OH, int OW, int CinP, int CoutP, WgradTileArgs* a);
