@@ -261,7 +261,9 @@ def main():
         fam = {}
         for kind, d, e0, e1, k in F.KERNEL_LOG:
             t, fl, cnt = fam.get(k, (0.0, 0.0, 0))
-            fam[k] = (t + e0.elapsed_time(e1) * 1e-3, fl + conv_flops(d), cnt + 1)
+            # one C-ABI call = one kernel launch, except a strided dgrad on the gather kernel (stride^2 parity classes)
+            nl = d[7] * d[7] if (kind == "dgrad" and k.startswith("conv_gemm")) else 1
+            fam[k] = (t + e0.elapsed_time(e1) * 1e-3, fl + conv_flops(d), cnt + nl)
         F.KERNEL_LOG = None
         if fam:
             top = max(fam, key=lambda k: fam[k][0])

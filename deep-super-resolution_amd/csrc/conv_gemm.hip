@@ -160,28 +160,38 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
   };
   // LDS-DMA variant of load_step: `buffer_load_dwordx4 ... lds` writes 64 lanes x 16 B = 8 tile rows straight into
   // the stage (an out-of-range offset writes zeros), so the operand tiles never pass through VGPRs.
-  [[maybe_unused]] auto dma_step = [&](int s, int stage) {
+  struct TapStep {   // wave-uniform decode of one K-step: tap offsets into the image and into the weight image
+    int dy, dx, toff, woff;
+  };
+  [[maybe_unused]] auto decode_step = [&](int s) {
     const int t = fd_div(a.fd_cu8, s);
     const int cbase = (s - t * cu8) * 64;
     const int tp = sTaps[t];
-    const int dy = (int)(signed char)(tp & 0xff);
-    const int dx = (int)(signed char)((tp >> 8) & 0xff);
+    TapStep d;
+    d.dy = (int)(signed char)(tp & 0xff);
+    d.dx = (int)(signed char)((tp >> 8) & 0xff);
     const int widx = (tp >> 16) & 0xffff;
-    const int toff = ((dy * a.IW + dx) * a.CinP + cbase) * 2;
-    const int woff = (widx * a.NB * a.CinP + cbase) * 2;
+    d.toff = ((d.dy * a.IW + d.dx) * a.CinP + cbase) * 2;
+    d.woff = (widx * a.NB * a.CinP + cbase) * 2;
+    return d;
+  };
+  [[maybe_unused]] auto dma_issue = [&](const TapStep& d, int stage) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const bool inb = (unsigned)(a_iy0[i] + dy) < (unsigned)a.IH && (unsigned)(a_ix0[i] + dx) < (unsigned)a.IW;
+      const bool inb = (unsigned)(a_iy0[i] + d.dy) < (unsigned)a.IH && (unsigned)(a_ix0[i] + d.dx) < (unsigned)a.IW;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(sA + stage * A_STAGE + (wave * 8 + RPP * i) * 128), 16,
-                                               inb ? (unsigned)(a_base[i] + toff) : OOB, 0, 0, 0);
+                                               inb ? (unsigned)(a_base[i] + d.toff) : OOB, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i)
       if (RPP * i < BN)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + stage * B_STAGE + (wave * 8 + RPP * i) * 128), 16,
-                                                 (unsigned)(b_base[i] + woff), 0, 0, 0);
+                                                 (unsigned)(b_base[i] + d.woff), 0, 0, 0);
   };
+  // LDS-DMA variant of load_step: `buffer_load_dwordx4 ... lds` writes 64 lanes x 16 B = 8 tile rows straight into
+  // the stage (an out-of-range offset writes zeros), so the operand tiles never pass through VGPRs.
+  [[maybe_unused]] auto dma_step = [&](int s, int stage) { dma_issue(decode_step(s), stage); };
   int st_off[RA > RB ? RA : RB];
 #pragma unroll
   for (int i = 0; i < (RA > RB ? RA : RB); ++i) {
@@ -258,12 +268,41 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
     };
     if constexpr (NSTAGE == 2) {
       dma_step(0, 0);
-      for (int s = 0; s < ks; ++s) {
+      TapStep nd = decode_step(ks > 1 ? 1 : 0);      // the tap table read of the NEXT step is kept out of the loop body's
+      for (int s = 0; s < ks; ++s) {                 // head: it shares the LDS counter with the fragment reads
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + 1 < ks) dma_step(s + 1, (s + 1) & 1);
-        compute_flat(s & 1);
+        // the first half-step's fragments are requested BEFORE the address arithmetic of the next DMA, which then runs
+        // under their LDS latency instead of in front of it
+        const int cur = s & 1;
+        const unsigned char* pa = sA + cur * A_STAGE + (wm * WM + r16) * 128;
+        const unsigned char* pb = sB + cur * B_STAGE + (wn * WN + r16) * 128;
+        U4 fa[TM], fb[TN];
+        {
+          const int slot = (g ^ sw) << 4;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const U4*>(pa + i * 16 * 128 + slot);
+#pragma unroll
+          for (int k = 0; k < TN; ++k) fb[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot);
+        }
+        if (s + 1 < ks) dma_issue(nd, cur ^ 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int k = 0; k < TN; ++k) acc[i][k] = mfma16<DT>(fa[i], fb[k], acc[i][k]);
+        if (s + 2 < ks) nd = decode_step(s + 2);
+        {
+          const int slot = ((4 + g) ^ sw) << 4;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const U4*>(pa + i * 16 * 128 + slot);
+#pragma unroll
+          for (int k = 0; k < TN; ++k) fb[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int k = 0; k < TN; ++k) acc[i][k] = mfma16<DT>(fa[i], fb[k], acc[i][k]);
       }
     } else {
       // three-stage ring, one resident block per CU: the DMA of step s+2 is issued before the MFMAs of step s, so a

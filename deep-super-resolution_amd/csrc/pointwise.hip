@@ -86,8 +86,17 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const float* __restri
   int r1 = r0 + rpc;
   if (r1 > rows) r1 = rows;
   double s = 0.0;
-  if (col < width)
-    for (int r = r0 + ry; r < r1; r += 4) s += (double)in[(size_t)r * width + col];
+  if (col < width) {
+    int r = r0 + ry;
+    for (; r + 28 < r1; r += 32) {          // 8 independent loads in flight, summed in row order (deterministic)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = in[(size_t)(r + 4 * u) * width + col];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; r < r1; r += 4) s += (double)in[(size_t)r * width + col];
+  }
   red[ry][cx] = s;
   __syncthreads();
   if (ry == 0 && col < width) out[(size_t)blockIdx.y * width + col] = (float)(red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
@@ -117,7 +126,15 @@ __global__ void sum_rows_kernel(const float* __restrict__ partial, int rows, int
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0.0;
-  for (int b = 0; b < rows; ++b) s += (double)partial[(size_t)b * row_stride + col_offset + c];
+  int b = 0;
+  for (; b + 8 <= rows; b += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = partial[(size_t)(b + u) * row_stride + col_offset + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (double)t[u];
+  }
+  for (; b < rows; ++b) s += (double)partial[(size_t)b * row_stride + col_offset + c];
   float v = (float)(s * (double)scale);
   out[c] = accumulate ? out[c] + v : v;
 }
@@ -140,7 +157,21 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int tiles,
     return;
   }
   double s1 = 0.0, s2 = 0.0;
-  for (int t = 0; t < tiles; ++t) {
+  int t = 0;
+  for (; t + 8 <= tiles; t += 8) {          // 16 independent loads in flight; summed in tile order
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = partial[((size_t)(t + u) * 2 + 0) * stride + c];
+      b[u] = partial[((size_t)(t + u) * 2 + 1) * stride + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s1 += (double)a[u];
+      s2 += (double)b[u];
+    }
+  }
+  for (; t < tiles; ++t) {
     s1 += (double)partial[((size_t)t * 2 + 0) * stride + c];
     s2 += (double)partial[((size_t)t * 2 + 1) * stride + c];
   }
@@ -336,7 +367,23 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int bl
   double acc_p = 0.0;
   for (int cc = c; cc < Cp; cc += blockDim.x) {
     double g = 0.0, gx = 0.0, p = 0.0;
-    for (int b = 0; b < blocks; ++b) {
+    int b = 0;
+    for (; b + 4 <= blocks; b += 4) {       // 12 independent loads in flight; summed in block order
+      float t0[4], t1[4], t2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        t0[u] = partial[((size_t)(b + u) * 3 + 0) * Cp + cc];
+        t1[u] = partial[((size_t)(b + u) * 3 + 1) * Cp + cc];
+        t2[u] = partial[((size_t)(b + u) * 3 + 2) * Cp + cc];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        g += (double)t0[u];
+        gx += (double)t1[u];
+        p += (double)t2[u];
+      }
+    }
+    for (; b < blocks; ++b) {
       g += (double)partial[((size_t)b * 3 + 0) * Cp + cc];
       gx += (double)partial[((size_t)b * 3 + 1) * Cp + cc];
       p += (double)partial[((size_t)b * 3 + 2) * Cp + cc];
