@@ -96,6 +96,7 @@ static inline int pack_tap(int dy, int dx, int widx) { return (dy & 0xff) | ((dx
 static void finish_args(ConvGemmArgs& a, int N, int wslices) {
   a.x_bytes = (unsigned)((size_t)N * a.IH * a.IW * a.CinP * 2);
   a.w_bytes = (unsigned)((size_t)wslices * a.NB * a.CinP * 2);
+  a.y_bytes = (unsigned)((size_t)N * a.OH * a.OW * a.CoutP * 2);
   a.CU = a.CinP / 8;
   a.U = a.ntaps * a.CU;
   a.ksteps = (a.U + 7) / 8;

@@ -17,6 +17,8 @@
 //    (out[n,2h+i,2w+j,c] = y[n,h,w,4c+2i+j], generator.py:32,38) or fp32 NCHW store for the last layer.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "dsr_common.h"
 #include "dsr_kernels.h"
 
@@ -29,7 +31,7 @@ struct ConvGemmLds {
   static constexpr int TOTAL = TILE + WGM * 2 * BN * 4 + DSR_MAX_TAPS * 4;
 };
 
-template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA, int NSTAGE>
+template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA, int NSTAGE, bool SWAP>
 __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) void conv_gemm_kernel(const ConvGemmArgs a) {
   static_assert(!DMA || FAST, "the LDS-DMA loader exists for the fast path only");
   static_assert(NSTAGE == 2 || (NSTAGE == 3 && DMA), "three stages: DMA ring only");
@@ -216,6 +218,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
   // tile of s+1 is in one register set (loaded two iterations ago) and the loads of s+2 are in flight in the
   // other.  An iteration = {write set(s+1) -> LDS[(s+1)&1]; issue loads of s+3 into that set; 32 MFMAs on
   // LDS[s&1]; barrier}: every global load gets two full iterations of MFMA work to land.
+  // bias of this tile's columns, requested before the K loop (its latency would otherwise sit in the epilogue)
+  float bias_r[TN][SWAP ? 4 : 1];
+#pragma unroll
+  for (int k = 0; k < TN; ++k)
+#pragma unroll
+    for (int jj = 0; jj < (SWAP ? 4 : 1); ++jj) {
+      const int col = n0 + wn * WN + 16 * k + (SWAP ? 4 * g + jj : r16);
+      bias_r[k][jj] = ((a.flags & DSR_F_BIAS) && col < a.cout) ? a.bias[col] : 0.f;
+    }
   const int ks = a.ksteps;
   if constexpr (!DMA) {
     load_step(0, ra0, rb0);
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int k = 0; k < TN; ++k) acc[i][k] = mfma16<DT>(fa[i], fb[k], acc[i][k]);
+        for (int k = 0; k < TN; ++k) acc[i][k] = SWAP ? mfma16<DT>(fb[k], fa[i], acc[i][k]) : mfma16<DT>(fa[i], fb[k], acc[i][k]);
     }
   };
   if constexpr (DMA) {
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int k = 0; k < TN; ++k) acc[i][k] = mfma16<DT>(fa[i], fb[k], acc[i][k]);
+          for (int k = 0; k < TN; ++k) acc[i][k] = SWAP ? mfma16<DT>(fb[k], fa[i], acc[i][k]) : mfma16<DT>(fa[i], fb[k], acc[i][k]);
       }
     };
     if constexpr (NSTAGE == 2) {
@@ -290,7 +301,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int k = 0; k < TN; ++k) acc[i][k] = mfma16<DT>(fa[i], fb[k], acc[i][k]);
+          for (int k = 0; k < TN; ++k) acc[i][k] = SWAP ? mfma16<DT>(fb[k], fa[i], acc[i][k]) : mfma16<DT>(fa[i], fb[k], acc[i][k]);
         if (s + 2 < ks) nd = decode_step(s + 2);
         {
           const int slot = ((4 + g) ^ sw) << 4;
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int k = 0; k < TN; ++k) acc[i][k] = mfma16<DT>(fa[i], fb[k], acc[i][k]);
+          for (int k = 0; k < TN; ++k) acc[i][k] = SWAP ? mfma16<DT>(fb[k], fa[i], acc[i][k]) : mfma16<DT>(fa[i], fb[k], acc[i][k]);
       }
     } else {
       // three-stage ring, one resident block per CU: the DMA of step s+2 is issued before the MFMAs of step s, so a
@@ -359,76 +370,177 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
   const bool nchw = (a.flags & DSR_F_OUT_NCHW_F32) != 0;
   unsigned char* sC = smem;
 
-  if (nchw) {
-    // fp32 NCHW store straight from the accumulators (last layers: Cout <= 16, so this is a small tensor)
-#pragma unroll
-    for (int k = 0; k < TN; ++k) {
-      const int col = n0 + wn * WN + 16 * k + r16;
-      const bool colok = col < a.cout;
-      const float bv = ((a.flags & DSR_F_BIAS) && colok) ? a.bias[col] : 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + wm * WM + 16 * i + 4 * g + r;
-          const float o = act_apply(a.act, acc[i][k][r] + bv, slope);
-          if (m < a.M && colok) {
-            int n = fd_div(a.fd_ghw, m);
-            int rem = m - n * (a.GH * a.GW);
-            int gy = fd_div(a.fd_gw, rem);
-            int gx = rem - gy * a.GW;
-            int oy = gy * a.osy + a.ooy, ox = gx * a.osx + a.oox;
-            a.out_f32[(((size_t)n * a.cout + col) * a.OH + oy) * a.OW + ox] = o;
+  if constexpr (SWAP) {
+    // Accumulator layout: the MFMA is issued with the WEIGHT fragment as its A operand, so D[m = channel][n = pixel]:
+    // acc[i][k][j] = out[row = wm*WM + 16i + r16][col = wn*WN + 16k + 4g + j].  A lane therefore owns 4 consecutive
+    // channels of one pixel: one packed 8-byte LDS write per 4 values (the pixel-major layout needs four 2-byte ones).
+    if (nchw) {
+      // fp32 NCHW store straight from the accumulators (last layers: Cout <= 16, so this is a small tensor)
+  #pragma unroll
+      for (int k = 0; k < TN; ++k) {
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = n0 + wn * WN + 16 * k + 4 * g + j;
+          const bool colok = col < a.cout;
+          const float bv = bias_r[k][SWAP ? j : 0];
+  #pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WM + 16 * i + r16;
+            const float o = act_apply(a.act, acc[i][k][j] + bv, slope);
+            if (m < a.M && colok) {
+              int n = fd_div(a.fd_ghw, m);
+              int rem = m - n * (a.GH * a.GW);
+              int gy = fd_div(a.fd_gw, rem);
+              int gx = rem - gy * a.GW;
+              int oy = gy * a.osy + a.ooy, ox = gx * a.osx + a.oox;
+              a.out_f32[(((size_t)n * a.cout + col) * a.OH + oy) * a.OW + ox] = o;
+            }
           }
         }
       }
+      return;
     }
-    return;
-  }
 
-  // the activation is selected ONCE (wave-uniform) and the 16-element-per-tile loop is instantiated per choice,
-  // so the hot loop carries no per-element branches
-  auto epilogue = [&](auto actf) {
-#pragma unroll
-    for (int k = 0; k < TN; ++k) {
-      const int ct = wn * WN + 16 * k + r16;   // column inside the block tile
-      const int col = n0 + ct;
-      const bool colok = col < a.cout;
-      const float bv = ((a.flags & DSR_F_BIAS) && colok) ? a.bias[col] : 0.f;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wm * WM + 16 * i + 4 * g + r;
-          const float v = acc[i][k][r] + bv;
-          const float vm = (m0 + row < a.M && colok) ? v : 0.f;   // statistics ignore tail rows / pad columns
-          s1 += vm;
-          s2 += vm * vm;
-          const float o = colok ? actf(v) : 0.f;
-          *reinterpret_cast<unsigned short*>(sC + row * C_STRIDE + ct * 2) = f2h<DT>(o);
+    // the activation (and whether statistics are wanted) is selected ONCE, wave-uniformly, and the per-element loop is
+    // instantiated per choice, so the hot loop carries no per-element branches and no dead statistics arithmetic
+    auto epilogue = [&](auto actf, auto stats_tag) {
+      constexpr bool ST = decltype(stats_tag)::value;
+  #pragma unroll
+      for (int k = 0; k < TN; ++k) {
+        const int ct0 = wn * WN + 16 * k + 4 * g;   // first of this lane's 4 columns inside the block tile
+        float bv[4], s1[4], s2[4];
+        bool cok[4];
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          cok[j] = n0 + ct0 + j < a.cout;
+          bv[j] = bias_r[k][SWAP ? j : 0];
+          s1[j] = s2[j] = 0.f;
+        }
+  #pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = wm * WM + 16 * i + r16;
+          const bool rok = m0 + row < a.M;
+          float o[4];
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v = acc[i][k][j] + bv[j];
+            if constexpr (ST) {
+              const float vm = (rok && cok[j]) ? v : 0.f;   // statistics ignore tail rows / pad columns
+              s1[j] += vm;
+              s2[j] += vm * vm;
+            }
+            o[j] = cok[j] ? actf(v) : 0.f;
+          }
+          uint2 h;
+          h.x = (unsigned)f2h<DT>(o[0]) | ((unsigned)f2h<DT>(o[1]) << 16);
+          h.y = (unsigned)f2h<DT>(o[2]) | ((unsigned)f2h<DT>(o[3]) << 16);
+          *reinterpret_cast<uint2*>(sC + row * C_STRIDE + ct0 * 2) = h;
+        }
+        if constexpr (ST) {
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) {
+  #pragma unroll
+            for (int x = 1; x < 16; x <<= 1) {          // over the 16 pixels (lanes r16) of the fragment
+              s1[j] += __shfl_xor(s1[j], x, 64);
+              s2[j] += __shfl_xor(s2[j], x, 64);
+            }
+          }
+          if (r16 == 0) {
+  #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              sStat[(wm * 2 + 0) * BN + ct0 + j] = s1[j];
+              sStat[(wm * 2 + 1) * BN + ct0 + j] = s2[j];
+            }
+          }
         }
       }
-      if (do_stats) {
-        s1 += __shfl_xor(s1, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 16, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (g == 0) {
-          sStat[(wm * 2 + 0) * BN + ct] = s1;
-          sStat[(wm * 2 + 1) * BN + ct] = s2;
+    };
+    auto run_epilogue = [&](auto actf) {
+      if (do_stats)
+        epilogue(actf, std::true_type{});
+      else
+        epilogue(actf, std::false_type{});
+    };
+    if (a.act == DSR_ACT_NONE)
+      run_epilogue([](float v) { return v; });
+    else if (a.act == DSR_ACT_RELU)
+      run_epilogue([](float v) { return v > 0.f ? v : 0.f; });
+    else if (a.act == DSR_ACT_LEAKY || a.act == DSR_ACT_PRELU)
+      run_epilogue([slope](float v) { return v >= 0.f ? v : v * slope; });
+    else
+      run_epilogue([&](float v) { return act_apply(a.act, v, slope); });
+  } else {
+    if (nchw) {
+      // fp32 NCHW store straight from the accumulators (last layers: Cout <= 16, so this is a small tensor)
+  #pragma unroll
+      for (int k = 0; k < TN; ++k) {
+        const int col = n0 + wn * WN + 16 * k + r16;
+        const bool colok = col < a.cout;
+        const float bv = bias_r[k][0];
+  #pragma unroll
+        for (int i = 0; i < TM; ++i) {
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * WM + 16 * i + 4 * g + r;
+            const float o = act_apply(a.act, acc[i][k][r] + bv, slope);
+            if (m < a.M && colok) {
+              int n = fd_div(a.fd_ghw, m);
+              int rem = m - n * (a.GH * a.GW);
+              int gy = fd_div(a.fd_gw, rem);
+              int gx = rem - gy * a.GW;
+              int oy = gy * a.osy + a.ooy, ox = gx * a.osx + a.oox;
+              a.out_f32[(((size_t)n * a.cout + col) * a.OH + oy) * a.OW + ox] = o;
+            }
+          }
         }
       }
+      return;
     }
-  };
-  if (a.act == DSR_ACT_NONE)
-    epilogue([](float v) { return v; });
-  else if (a.act == DSR_ACT_RELU)
-    epilogue([](float v) { return v > 0.f ? v : 0.f; });
-  else if (a.act == DSR_ACT_LEAKY || a.act == DSR_ACT_PRELU)
-    epilogue([slope](float v) { return v >= 0.f ? v : v * slope; });
-  else
-    epilogue([&](float v) { return act_apply(a.act, v, slope); });
+
+    // the activation is selected ONCE (wave-uniform) and the 16-element-per-tile loop is instantiated per choice,
+    // so the hot loop carries no per-element branches
+    auto epilogue = [&](auto actf) {
+  #pragma unroll
+      for (int k = 0; k < TN; ++k) {
+        const int ct = wn * WN + 16 * k + r16;   // column inside the block tile
+        const int col = n0 + ct;
+        const bool colok = col < a.cout;
+        const float bv = bias_r[k][0];
+        float s1 = 0.f, s2 = 0.f;
+  #pragma unroll
+        for (int i = 0; i < TM; ++i) {
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = wm * WM + 16 * i + 4 * g + r;
+            const float v = acc[i][k][r] + bv;
+            const float vm = (m0 + row < a.M && colok) ? v : 0.f;   // statistics ignore tail rows / pad columns
+            s1 += vm;
+            s2 += vm * vm;
+            const float o = colok ? actf(v) : 0.f;
+            *reinterpret_cast<unsigned short*>(sC + row * C_STRIDE + ct * 2) = f2h<DT>(o);
+          }
+        }
+        if (do_stats) {
+          s1 += __shfl_xor(s1, 16, 64);
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 16, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          if (g == 0) {
+            sStat[(wm * 2 + 0) * BN + ct] = s1;
+            sStat[(wm * 2 + 1) * BN + ct] = s2;
+          }
+        }
+      }
+    };
+    if (a.act == DSR_ACT_NONE)
+      epilogue([](float v) { return v; });
+    else if (a.act == DSR_ACT_RELU)
+      epilogue([](float v) { return v > 0.f ? v : 0.f; });
+    else if (a.act == DSR_ACT_LEAKY || a.act == DSR_ACT_PRELU)
+      epilogue([slope](float v) { return v >= 0.f ? v : v * slope; });
+    else
+      epilogue([&](float v) { return act_apply(a.act, v, slope); });
+  }
   __syncthreads();
 
   if (do_stats) {
@@ -498,10 +610,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
   }
 }
 
-template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA, int NSTAGE>
-static void launch_variant(dim3 grid, const ConvGemmArgs& b, hipStream_t st) {
+template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA, int NSTAGE, bool SWAP>
+static void launch_swap(dim3 grid, const ConvGemmArgs& b, hipStream_t st) {
   constexpr int LDS = ConvGemmLds<BM, BN, WGM, NSTAGE>::TOTAL;
-  auto* fn = conv_gemm_kernel<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE>;
+  auto* fn = conv_gemm_kernel<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE, SWAP>;
   if constexpr (LDS > 64 * 1024) {   // more than 64 KB of dynamic LDS needs the opt-in, once per kernel (not a stream op)
     static bool done = false;
     if (!done) {
@@ -510,6 +622,16 @@ static void launch_variant(dim3 grid, const ConvGemmArgs& b, hipStream_t st) {
     }
   }
   hipLaunchKernelGGL(fn, grid, dim3(64 * WGM * WGN), LDS, st, b);
+}
+
+// Launches that want BatchNorm statistics keep the pixel-major accumulator layout (a channel's column sum is then an
+// in-lane sum plus two shuffles); all others use the channel-major one (SWAP: packed 8-byte C-tile writes).
+template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA, int NSTAGE>
+static void launch_variant(dim3 grid, const ConvGemmArgs& b, hipStream_t st) {
+  if (b.flags & DSR_F_STATS)
+    launch_swap<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE, false>(grid, b, st);
+  else
+    launch_swap<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE, true>(grid, b, st);
 }
 
 static bool env_on(const char* name) {   // tuning switches, default on ("0" turns one off)
@@ -563,6 +685,7 @@ static void dispatch_dt(const ConvGemmArgs& a, hipStream_t st) {
 }
 
 void dsr_launch_conv_gemm(const ConvGemmArgs& a, int dtype, hipStream_t st) {
+  if (dsr_launch_conv_gemm_persist(a, dtype, st)) return;   // many-tile fast-path launches: persistent kernel
   if (dtype == DSR_DTYPE_BF16)
     dispatch_dt<DSR_DTYPE_BF16>(a, st);
   else

@@ -40,6 +40,7 @@ struct ConvGemmArgs {
   const float* prelu;  // 1 float
   float* stats;        // [tiles_m][2][stats_stride]
   unsigned x_bytes, w_bytes;   // buffer sizes for the hardware range check of the operand loads
+  unsigned y_bytes;            // size of y (range-checked buffer stores of the persistent kernel)
   int M, GH, GW;
   int IH, IW, CinP;
   int OH, OW, CoutP;
@@ -57,6 +58,7 @@ struct ConvGemmArgs {
 };
 
 void dsr_launch_conv_gemm(const ConvGemmArgs& a, int dtype, hipStream_t st);
+bool dsr_launch_conv_gemm_persist(const ConvGemmArgs& a, int dtype, hipStream_t st);   // conv_gemm_persist.hip
 
 struct WgradArgs {
   const void* x;    // [N][IH][IW][CinP]

@@ -344,3 +344,70 @@ def test_adam_multi_tensor_matches_per_tensor(dev):
     for i in range(len(shapes)):
         assert rel_err(a[i].detach().cpu(), b[i].detach().cpu()) < 1e-6, i      # FMA contraction may differ by an ulp
         assert rel_err(a[i].detach().cpu(), r[i].detach()) < 1e-6, i
+
+
+PERSIST_CASES = [  # name, N, H, W, Cin, Cout, stride, act, stats, pixel_shuffle
+    ("fwd_128_stats", 4, 192, 192, 64, 128, 1, 0, True, False),
+    ("fwd_128_leaky", 4, 192, 192, 64, 128, 1, 1, False, False),
+    ("fwd_256_pixshuf", 4, 192, 192, 64, 256, 1, 2, False, True),
+    ("fwd_64_s2", 6, 400, 368, 64, 64, 2, 1, True, False),          # persistent 128x64 forward (stats) + 4 dgrad classes
+    ("fwd_64_s1_relu", 3, 272, 260, 128, 64, 1, 3, False, False),    # persistent forward, channel-major C tile
+    ("dgrad_256_64", 4, 192, 192, 64, 256, 1, 0, False, False),      # dgrad of the PixelShuffle conv: 36 K-steps, N = 64
+    ("fwd_192_ragged", 5, 190, 170, 128, 192, 1, 3, False, False),
+]
+
+
+@pytest.mark.parametrize("case", PERSIST_CASES, ids=[c[0] for c in PERSIST_CASES])
+def test_persistent_conv_equals_per_image_launches(dev, case):
+    """64-wide GEMMs with at least two tiles per resident block run on conv_gemm_persist_kernel (tile loop, C tile
+    in the last stage, counted vmcnt across the tile boundary); the same convolution issued one image at a time stays
+    on the one-tile-per-block kernel.  Both must agree BIT FOR BIT (forward, statistics sums, input gradient); the
+    128-wide cases check the same batch-split invariance on the one-tile kernel."""
+    import ctypes as C
+    L = P("_lib")
+    lib = L.lib()
+    _, n, h, w, cin, cout, stride, act, stats, ps = case
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(7)
+    x = (torch.rand(n, h, w, cin, device=dev) - 0.5).to(torch.bfloat16)
+    wt = (torch.rand(cout, cin, 3, 3, device=dev) - 0.5) * 0.2
+    bias = torch.rand(cout, device=dev) - 0.5
+    prelu = torch.tensor([0.2], device=dev)
+
+    def run(xb):
+        nb = xb.shape[0]
+        d = L.ConvDesc(L.BF16, nb, h, w, cin, cout, 3, 3, stride, 1, 0)
+        oh, ow = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+        wf = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 0), dtype=torch.bfloat16, device=dev)
+        wd = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 1), dtype=torch.bfloat16, device=dev)
+        L.check(lib.dsr_conv_pack_weight(C.byref(d), ptr(wt), ptr(wf), ptr(wd), st))
+        if ps:
+            y = torch.full((nb, 2 * oh, 2 * ow, cout // 4), float("nan"), dtype=torch.bfloat16, device=dev)
+        else:
+            y = torch.full((nb, oh, ow, cout), float("nan"), dtype=torch.bfloat16, device=dev)
+        rows = lib.dsr_conv_stats_rows(C.byref(d))
+        part = torch.zeros((rows + 64) * 2 * cout, dtype=torch.float32, device=dev) if stats else None
+        ep = L.Epilogue(act, 0.2, ptr(prelu) if act == 2 else None, ptr(bias), ptr(part), int(ps), None)
+        L.check(lib.dsr_conv_fwd(C.byref(d), ptr(xb), ptr(wf), C.byref(ep), ptr(y), st))
+        ssum = part[: rows * 2 * cout].view(rows, 2, cout).double().sum(0) if stats else None
+        dx = None
+        if not ps:
+            dy = y.clone()          # any finite tensor of the output shape
+            dx = torch.full_like(xb, float("nan"))
+            wsz = lib.dsr_conv_dgrad_workspace(C.byref(d))
+            ws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=dev)
+            L.check(lib.dsr_conv_dgrad(C.byref(d), ptr(dy), ptr(wd), ptr(dx), ptr(ws), wsz, st))
+        return y, ssum, dx
+
+    y_all, s_all, dx_all = run(x)
+    ys, ss, dxs = zip(*[run(x[i:i + 1].contiguous()) for i in range(n)])
+    torch.cuda.synchronize()
+    assert torch.isfinite(y_all.float()).all()
+    assert torch.equal(y_all, torch.cat(ys))
+    if stats:
+        ref = sum(ss)
+        assert (s_all - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+    if dx_all is not None:
+        assert torch.isfinite(dx_all.float()).all()
+        assert torch.equal(dx_all, torch.cat(dxs))
