@@ -118,7 +118,8 @@ def build_step(workload, dev, world):
     sync_d = D.GradSync(disc.parameters()).attach()
 
     def step():
-        return steps.gan_step(gen, disc, perc, opt_g, opt_d, lr, hr, sync_g, sync_d)[1]
+        return steps.gan_step(gen, disc, perc, opt_g, opt_d, lr, hr, sync_g, sync_d,
+                              overlap=os.environ.get("DSR_GAN_OVERLAP", "1") != "0")[1]
     return step, n * (s * f) ** 2
 
 

@@ -18,34 +18,80 @@ def gen_l1_step(gen, opt, lr_patches, hr_patches):
     return loss.detach(), fake.detach()
 
 
-def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g=None, sync_d=None):
-    """train_GAN.py:38-71.  Returns (loss_D, loss_G, fake) as device tensors (no host sync here)."""
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g=None, sync_d=None, overlap=True):
+    """train_GAN.py:38-71.  Returns (loss_D, loss_G, fake) as device tensors (no host sync here).
+
+    Once `fake` exists the reference's two halves are independent: the D step (:44-53) reads only `fake.detach()`,
+    and the G step's gradient comes only from the VGG content term -- the adversarial term is computed from a
+    DETACHED generator output (:58), so it contributes a number to loss_G (:59) and nothing to loss_G.backward()
+    (:63).  With `overlap` the D step (+ the no_grad D pass that feeds that number) runs on a second HIP stream
+    while VGG forward/backward, the generator backward and its Adam run on the main one: the HBM-bound BatchNorm /
+    Adam passes of one half execute under the MFMA-bound convolutions of the other.  The arithmetic is unchanged."""
     # train_GAN.py:46 and :56 evaluate gen(lr_patches) twice with the same weights and batch statistics -- the
     # two outputs are bit-identical and only the BatchNorm running statistics notice the second call.  One forward
     # (with the autograd graph the G step needs) + a double running-stat update is exactly equivalent.
+    main = torch.cuda.current_stream(hr_patches.device)
+    side = _side_stream(hr_patches.device) if overlap else main
+    hr_feat = None
+    if overlap:
+        # the VGG features of the HR target depend on nothing but the batch: they run beside the generator forward
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            hr_feat = perceptual.vgg_loss.target_features(hr_patches)
+            hr_feat_ready = torch.cuda.Event()
+            hr_feat_ready.record(side)
     gen.bn_updates = 2
     fake = gen(lr_patches)                                       # :46 and :56
     gen.bn_updates = 1
-    # --- discriminator
-    real_d, fake_d = disc.forward_pair(hr_patches, fake.detach())   # :44, :47 (BN statistics per batch, as there)
-    loss_d = F.bce_const(real_d, 1.0) + F.bce_const(fake_d, 0.0)  # :48, utils/GAN.py:101-105
-    opt_d.zero_grad()                                            # :51 (gan_D.zero_grad())
-    loss_d.backward()                                            # :52
-    if sync_d is not None:
-        sync_d()
-    opt_d.step()                                                 # :53
-    # --- generator
-    with torch.no_grad():
-        # :58 detaches the generator output, so this D pass never sends a gradient anywhere that survives
-        # (D's .grad from it is wiped by the next zero_grad, :51); it still updates D's BN running statistics.
-        fake_d = disc(fake.detach())
-    loss_g = perceptual(fake, hr_patches, fake_d, None)          # :59
+    fake_det = fake.detach()
+    if overlap:
+        side.wait_stream(main)                                   # `fake` is complete before D reads it
+
+    def d_half():
+        real_d, fake_d = disc.forward_pair(hr_patches, fake_det)     # :44, :47 (BN statistics per batch, as there)
+        loss_d = F.bce_const(real_d, 1.0) + F.bce_const(fake_d, 0.0)  # :48, utils/GAN.py:101-105
+        opt_d.zero_grad()                                        # :51 (gan_D.zero_grad())
+        loss_d.backward()                                        # :52
+        if sync_d is not None:
+            sync_d()
+        opt_d.step()                                             # :53
+        with torch.no_grad():
+            # :58 detaches the generator output, so this D pass never sends a gradient anywhere that survives
+            # (D's .grad from it is wiped by the next zero_grad, :51); it still updates D's BN running statistics.
+            adv = perceptual.adversarial(disc(fake_det))         # the adversarial number of :59
+        return loss_d.detach(), adv
+
+    if overlap:
+        with torch.cuda.stream(side):
+            loss_d, adv = d_half()
+    else:
+        loss_d, adv = d_half()
+    # --- generator (main stream)
+    if hr_feat is not None:
+        main.wait_event(hr_feat_ready)   # only the target features are needed here, not the D half queued behind them
+        hr_feat.record_stream(main)
+    content = perceptual.content(fake, hr_patches, hr_feat)      # the only term of :59 with a gradient path
     opt_g.zero_grad()                                            # :62
-    loss_g.backward()                                            # :63
+    content.backward()                                           # :63 (d adversarial / d generator == 0, see above)
     if sync_g is not None:
         sync_g()
     opt_g.step()                                                 # :64
-    return loss_d.detach(), loss_g.detach(), fake.detach()
+    if overlap:
+        main.wait_stream(side)                                   # D half done before anything later on `main`
+        loss_d.record_stream(main)
+        adv.record_stream(main)
+    loss_g = content.detach() + adv                              # :59 value (unweighted sum, utils/GAN.py:122)
+    return loss_d, loss_g, fake_det
 
 
 class DipRunner:

@@ -161,12 +161,19 @@ class Vgg19Loss(nn.Module):
                 i += 1
         return F.ToNCHW.apply(x, 512)
 
-    def forward(self, image1, image2):
+    def target_features(self, image2):
+        """Features of the HR target (:84-88): no gradient is ever used, so they can be computed ahead of time."""
+        with torch.no_grad():
+            return self.features(image2)
+
+    def forward(self, image1, image2, features2=None):
         feature_map1 = self.features(image1)                      # :82,86
-        with torch.no_grad():                                     # image2 is the HR target: no gradient is ever used
-            feature_map2 = self.features(image2) if not image2.requires_grad else None
-        if feature_map2 is None:
+        if features2 is not None:
+            feature_map2 = features2
+        elif image2.requires_grad:
             feature_map2 = self.features(image2)
+        else:
+            feature_map2 = self.target_features(image2)
         return F.mse_loss(feature_map1, feature_map2)             # :90
 
 
@@ -183,7 +190,13 @@ class PerceptualLoss(nn.Module):
         super(PerceptualLoss, self).__init__()
         self.vgg_loss = Vgg19Loss(vgg_state_dict, resize_to, crop)
 
+    def content(self, fake_output_G, HR_images, hr_features=None):
+        return self.vgg_loss(fake_output_G, HR_images, hr_features)   # :119
+
+    def adversarial(self, fake_output_D, bce_loss=None):
+        return get_adversarial_loss(fake_output_D, bce_loss)      # :120
+
     def forward(self, fake_output_G, HR_images, fake_output_D, bce_loss=None):
-        content_loss = self.vgg_loss(fake_output_G, HR_images)
-        adversarial_loss_ = get_adversarial_loss(fake_output_D, bce_loss)
+        content_loss = self.content(fake_output_G, HR_images)
+        adversarial_loss_ = self.adversarial(fake_output_D, bce_loss)
         return content_loss + adversarial_loss_                   # unweighted sum (:122)
