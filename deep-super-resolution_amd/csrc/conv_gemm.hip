@@ -218,15 +218,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
   // tile of s+1 is in one register set (loaded two iterations ago) and the loads of s+2 are in flight in the
   // other.  An iteration = {write set(s+1) -> LDS[(s+1)&1]; issue loads of s+3 into that set; 32 MFMAs on
   // LDS[s&1]; barrier}: every global load gets two full iterations of MFMA work to land.
-  // bias of this tile's columns, requested before the K loop (its latency would otherwise sit in the epilogue)
+  // bias of this tile's columns: the DMA variants (which have registers to spare) request it before the K loop, so
+  // its latency does not sit in the epilogue; the register-staged variants are at their occupancy edge (159 VGPRs, three
+  // blocks per CU for the 128x64 tile) and read it where it is used
+  constexpr bool PRELOAD_BIAS = DMA;
   float bias_r[TN][SWAP ? 4 : 1];
+  auto bias_at = [&](int k, int jj) {
+    const int col = n0 + wn * WN + 16 * k + (SWAP ? 4 * g + jj : r16);
+    return ((a.flags & DSR_F_BIAS) && col < a.cout) ? a.bias[col] : 0.f;
+  };
+  if constexpr (PRELOAD_BIAS) {
 #pragma unroll
-  for (int k = 0; k < TN; ++k)
+    for (int k = 0; k < TN; ++k)
 #pragma unroll
-    for (int jj = 0; jj < (SWAP ? 4 : 1); ++jj) {
-      const int col = n0 + wn * WN + 16 * k + (SWAP ? 4 * g + jj : r16);
-      bias_r[k][jj] = ((a.flags & DSR_F_BIAS) && col < a.cout) ? a.bias[col] : 0.f;
-    }
+      for (int jj = 0; jj < (SWAP ? 4 : 1); ++jj) bias_r[k][jj] = bias_at(k, jj);
+  }
+  [[maybe_unused]] auto bias_of = [&](int k, int jj) { return PRELOAD_BIAS ? bias_r[k][jj] : bias_at(k, jj); };
   const int ks = a.ksteps;
   if constexpr (!DMA) {
     load_step(0, ra0, rb0);
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
         for (int j = 0; j < 4; ++j) {
           const int col = n0 + wn * WN + 16 * k + 4 * g + j;
           const bool colok = col < a.cout;
-          const float bv = bias_r[k][SWAP ? j : 0];
+          const float bv = bias_of(k, SWAP ? j : 0);
   #pragma unroll
           for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm * WM + 16 * i + r16;
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
   #pragma unroll
         for (int j = 0; j < 4; ++j) {
           cok[j] = n0 + ct0 + j < a.cout;
-          bv[j] = bias_r[k][SWAP ? j : 0];
+          bv[j] = bias_of(k, SWAP ? j : 0);
           s1[j] = s2[j] = 0.f;
         }
   #pragma unroll
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
       for (int k = 0; k < TN; ++k) {
         const int col = n0 + wn * WN + 16 * k + r16;
         const bool colok = col < a.cout;
-        const float bv = bias_r[k][0];
+        const float bv = bias_of(k, 0);
   #pragma unroll
         for (int i = 0; i < TM; ++i) {
   #pragma unroll
@@ -505,7 +512,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
         const int ct = wn * WN + 16 * k + r16;   // column inside the block tile
         const int col = n0 + ct;
         const bool colok = col < a.cout;
-        const float bv = bias_r[k][0];
+        const float bv = bias_of(k, 0);
         float s1 = 0.f, s2 = 0.f;
   #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -628,10 +635,14 @@ static void launch_swap(dim3 grid, const ConvGemmArgs& b, hipStream_t st) {
 // in-lane sum plus two shuffles); all others use the channel-major one (SWAP: packed 8-byte C-tile writes).
 template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA, int NSTAGE>
 static void launch_variant(dim3 grid, const ConvGemmArgs& b, hipStream_t st) {
-  if (b.flags & DSR_F_STATS)
-    launch_swap<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE, false>(grid, b, st);
-  else
-    launch_swap<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE, true>(grid, b, st);
+  if constexpr (DMA) {
+    if (!(b.flags & DSR_F_STATS)) {
+      launch_swap<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE, true>(grid, b, st);
+      return;
+    }
+  }
+  // statistics launches, and the register-staged variants (measured 10 % slower with the channel-major epilogue)
+  launch_swap<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE, false>(grid, b, st);
 }
 
 static bool env_on(const char* name) {   // tuning switches, default on ("0" turns one off)

@@ -157,6 +157,151 @@ __global__ __launch_bounds__(512, 2) void conv_smalln_kernel(const SmallNArgs a)
   }
 }
 
+// ------------------------------------------------------------------ 9x9, 64 -> <=3 channels: Toeplitz column mapping
+// conv_smalln_kernel feeds one tap per MFMA with 3 of its 16 output columns useful.  Here the kw offsets go into the
+// GEMM's N dimension instead: for tap row kh and kw group G (kw = 0..4 | 5..8),
+//     T_G[p][(d, co)] = sum_kh sum_ci in[y + kh][p][ci] * W[kh][kwbase_G + d][ci][co]         (p = input column)
+// is one GEMM with N = 5 shifts x 3 channels = 15 columns and K = 9 x 64, and the output is the diagonal sum
+//     out[y][x][co] = sum_G sum_d T_G[x + kwbase_G + d][(d, co)].
+// 108 MFMAs and 90 fragment reads per 32 output pixels instead of 324 and 486.  T is written to LDS (aliasing the
+// halo, which is dead by then) with a 17-float row pitch and summed by the wave that produced it.
+template <int DT>
+__global__ __launch_bounds__(512, 2) void conv_toeplitz9_kernel(const SmallNArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TR = 8, HR = TR + 8, HC = 40;
+  constexpr int W_BYTES = 18 * 16 * 128;                 // [kh][group][16 rows][64 ci], chunks XOR-swizzled by row
+  constexpr int T_PITCH = 17, T_WAVE = 2 * 48 * T_PITCH; // floats per wave: [group][48 p][17]
+  unsigned char* sW = smem;
+  unsigned char* sX = smem + W_BYTES;                    // [HR][HC][64 ch] (80 KB); reused as float sT[8 waves][T_WAVE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, r16 = lane & 15;
+  const int per_img = a.tiles_y * a.tiles_x;
+  const unsigned short* __restrict__ Wg = reinterpret_cast<const unsigned short*>(a.w);
+  const int c = tid & 7, pb = tid >> 3;
+
+  // weights: LDS row (kh, G, n = 3d + co) <- packed slice [tap = 9kh + kwbase + d][row co]; unused rows are zero
+  for (int i = tid; i < 18 * 16 * 8; i += 512) {
+    const int ch = i & 7, row = (i >> 3) & 15, kg = i >> 7;
+    const int kh = kg >> 1, G = kg & 1;
+    const int d = row / 3, co = row - 3 * d;
+    const int kw = 5 * G + d;
+    const bool ok = row < 15 && kw < 9 && co < a.cout;
+    U4 v = U4{0u, 0u, 0u, 0u};
+    if (ok) v = reinterpret_cast<const U4*>(Wg)[((kh * 9 + kw) * a.NB + co) * 8 + ch];
+    *reinterpret_cast<U4*>(sW + (kg * 16 + row) * 128 + ((ch ^ (row & 7)) << 4)) = v;
+  }
+  int b_off[2];                                          // B fragment: row r16, k-chunk 4kk + g
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) b_off[kk] = r16 * 128 + (((4 * kk + g) ^ (r16 & 7)) << 4);
+  int a_off[3][2];                                       // A fragment: input column p = 16f + r16 (clamped to the halo row)
+#pragma unroll
+  for (int f = 0; f < 3; ++f) {
+    const int p = 16 * f + r16 < HC ? 16 * f + r16 : HC - 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) a_off[f][kk] = p * 128 + (((4 * kk + g) ^ (p & 7)) << 4);
+  }
+
+  constexpr int NV = (HR * HC * 8 + 511) / 512;          // 10 halo vectors per thread
+  const int hr0 = pb / HC, hc0 = pb - hr0 * HC;
+  U4 v[NV];
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  auto fetch = [&](int t) {
+    const int n = t / per_img;
+    const int rem = t - n * per_img;
+    const int oy0 = (rem / a.tiles_x) * TR - 4, ox0 = (rem % a.tiles_x) * 32 - 4;
+    int hr = hr0, hc = hc0;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int iy = oy0 + hr, ix = ox0 + hc;
+      const bool ok = hr < HR && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      v[u] = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(
+                                        xrsrc, ok ? (unsigned)((((n * a.IH + iy) * a.IW + ix) * 64 + c * 8) * 2) : OOB, 0, 0));
+      hc += 64;
+      while (hc >= HC) {
+        hc -= HC;
+        ++hr;
+      }
+    }
+  };
+  auto stash = [&]() {
+    int hr = hr0, hc = hc0;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int q = hr * HC + hc;
+      if (hr < HR) *reinterpret_cast<U4*>(sX + q * 128 + ((c ^ (q & 7)) << 4)) = v[u];
+      hc += 64;
+      while (hc >= HC) {
+        hc -= HC;
+        ++hr;
+      }
+    }
+  };
+  const float slope = a.prelu ? a.prelu[0] : a.slope;
+  float* sT = reinterpret_cast<float*>(sX) + wave * T_WAVE;
+
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tstep = gridDim.x;
+  if (t < a.ntiles) fetch(t);
+  for (; t < a.ntiles; t += tstep) {
+    __syncthreads();                                     // previous tile's T reads are done (and sW is written)
+    stash();
+    __syncthreads();
+    if (t + tstep < a.ntiles) fetch(t + tstep);
+
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) acc[f][0] = acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 9; ++kh) {
+      const unsigned char* rowp = sX + (wave + kh) * HC * 128;
+      const unsigned char* wp = sW + kh * 2 * 16 * 128;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        U4 fa[3], fb[2];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) fa[f] = *reinterpret_cast<const U4*>(rowp + a_off[f][kk]);
+#pragma unroll
+        for (int G = 0; G < 2; ++G) fb[G] = *reinterpret_cast<const U4*>(wp + G * 16 * 128 + b_off[kk]);
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+          for (int G = 0; G < 2; ++G) acc[f][G] = mfma16<DT>(fa[f], fb[G], acc[f][G]);
+      }
+    }
+    __syncthreads();                                     // every wave is done with the halo: it becomes T
+    // lane (g, r16) holds T_G[p = 16f + 4g + j][n = r16]
+#pragma unroll
+    for (int G = 0; G < 2; ++G)
+#pragma unroll
+      for (int f = 0; f < 3; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sT[(G * 48 + 16 * f + 4 * g + j) * T_PITCH + r16] = acc[f][G][j];
+    // (the wave reads back only what it wrote itself: LDS operations of one wave complete in order)
+    const int n = t / per_img;
+    const int rem = t - n * per_img;
+    const int oy = (rem / a.tiles_x) * TR + wave, ox0 = (rem % a.tiles_x) * 32;
+    if (lane < 32 && oy < a.OH && ox0 + lane < a.OW) {
+      const int x = lane;
+#pragma unroll
+      for (int co = 0; co < 3; ++co) {
+        if (co < a.cout) {
+          float s = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+          for (int d = 0; d < 5; ++d) s += sT[(x + d) * T_PITCH + 3 * d + co];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) s += sT[(48 + x + 5 + d) * T_PITCH + 3 * d + co];
+          const float o = act_apply(a.act, s, slope);
+          if (a.out_f32)
+            a.out_f32[(((size_t)n * a.cout + co) * a.OH + oy) * a.OW + ox0 + x] = o;
+          else
+            reinterpret_cast<unsigned short*>(a.y)[((size_t)(n * a.OH + oy) * a.OW + ox0 + x) * a.CoutP + co] = f2h<DT>(o);
+        }
+      }
+    }
+  }
+}
+
 // zero the pad channels [cout, CoutP) of a 16-bit NHWC output written column-wise by conv_smalln_kernel
 template <int DT>
 __global__ void zero_pad_channels_kernel(unsigned short* __restrict__ y, size_t P, int cout, int CoutP) {
@@ -188,6 +333,29 @@ int dsr_launch_conv_smalln(SmallNArgs& a, int N, int dtype, hipStream_t st) {
   }
   const size_t P = (size_t)N * a.OH * a.OW;
   const bool zpad = !a.out_f32 && a.cout < a.CoutP;
+  if (a.KW == 9 && a.KH == 9 && a.cout <= 3 && a.pad == 4 && !a.flip) {   // the generator's tail: Toeplitz mapping
+    static bool attr_done[2] = {false, false};
+    const int dj = dtype == DSR_DTYPE_BF16 ? 0 : 1;
+    const size_t tl = 18 * 16 * 128 + 16 * 40 * 128;
+    const void* tf = dj == 0 ? (const void*)conv_toeplitz9_kernel<DSR_DTYPE_BF16> : (const void*)conv_toeplitz9_kernel<DSR_DTYPE_F16>;
+    if (!attr_done[dj]) {
+      (void)hipFuncSetAttribute(tf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done[dj] = true;
+    }
+    dim3 tg(a.ntiles < 256 ? a.ntiles : 256);
+    if (dj == 0) {
+      hipLaunchKernelGGL((conv_toeplitz9_kernel<DSR_DTYPE_BF16>), tg, block, tl, st, a);
+      if (zpad)
+        hipLaunchKernelGGL((zero_pad_channels_kernel<DSR_DTYPE_BF16>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
+                           (unsigned short*)a.y, P, a.cout, a.CoutP);
+    } else {
+      hipLaunchKernelGGL((conv_toeplitz9_kernel<DSR_DTYPE_F16>), tg, block, tl, st, a);
+      if (zpad)
+        hipLaunchKernelGGL((zero_pad_channels_kernel<DSR_DTYPE_F16>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
+                           (unsigned short*)a.y, P, a.cout, a.CoutP);
+    }
+    return 1;
+  }
   if (dtype == DSR_DTYPE_BF16) {
     if (a.KW == 9)
       hipLaunchKernelGGL((conv_smalln_kernel<DSR_DTYPE_BF16, 9>), grid, block, lds, st, a);
