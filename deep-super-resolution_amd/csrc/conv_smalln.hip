@@ -392,15 +392,15 @@ template <int DT, int KW, int KHB, int CT, int IT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(const WgradTileArgs a, int KH) {
   constexpr int R = 2;
   constexpr int HR = R - 1 + KHB, HC = 31 + KW;
+  static_assert((HR * HC) % 32 == 0 && HC % 8 == 0, "halo slots must fill whole DMA instructions");
   constexpr int NTB = KHB * KW;
   constexpr int NW = (NTB + 3) / 4;
-  __shared__ __attribute__((aligned(16))) unsigned char sX[HR * HC * 128];
-  __shared__ __attribute__((aligned(16))) unsigned char sY[R * 32 * 128];
+  constexpr int XB = HR * HC * 128, YB = R * 32 * 128, STAGE = XB + YB;
+  // one LDS object, two stages: the next tile's halo and dY tile arrive by LDS-DMA under this tile's MFMAs
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
   const int kh0 = blockIdx.y * KHB;
-  const unsigned short* __restrict__ X = reinterpret_cast<const unsigned short*>(a.x);
-  const unsigned short* __restrict__ DY = reinterpret_cast<const unsigned short*>(a.dy);
 
   f32x4 acc[NW][CT][IT];
 #pragma unroll
@@ -410,43 +410,50 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(const WgradTile
 #pragma unroll
       for (int j = 0; j < IT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int c = tid & 7, pbase = tid >> 3;
+  // DMA role: slot position (lane & 7) of pixel slot q = 32u + 8*wave + (lane >> 3) holds chunk (lane & 7) ^ (q & 7)
+  const int c = (tid & 7) ^ ((tid >> 3) & 7), pbase = tid >> 3;
   const bool yc_ok = (c * 8) < a.CoutP && c * 8 < CT * 16, xc_ok = (c * 8) < a.CinP && c * 8 < IT * 16;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
   int t_end = (blockIdx.z + 1) * a.tiles_per_block;
   if (t_end > a.ntiles) t_end = a.ntiles;
   const int per_img = a.tiles_y * a.tiles_x;
-
-  for (int t = blockIdx.z * a.tiles_per_block; t < t_end; ++t) {
+  auto dma = [&](int t, int buf) {
     const int n = t / per_img;
     const int rem = t - n * per_img;
     const int oy0 = (rem / a.tiles_x) * R, ox0 = (rem % a.tiles_x) * 32;
-    __syncthreads();
+    unsigned char* st = smem + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < R * 32 * 8 / 256; ++i) {
-      const int p = pbase + 32 * i;
+    for (int u = 0; u < (HR * HC) / 32; ++u) {
+      const int q = pbase + 32 * u;
+      const int hr = q / HC, hc = q - hr * HC;
+      const int iy = oy0 + hr + kh0 - a.pad, ix = ox0 + hc - a.pad;
+      const bool ok = xc_ok && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(st + (32 * u + 8 * wave) * 128), 16,
+                                               ok ? (unsigned)((((n * a.IH + iy) * a.IW + ix) * a.CinP + c * 8) * 2) : OOB, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < (R * 32) / 32; ++u) {
+      const int p = pbase + 32 * u;
       const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
       const bool ok = yc_ok && oy < a.OH && ox < a.OW;
-      U4 v = load16_or_zero(DY, ((size_t)(n * a.OH + oy) * a.OW + ox) * a.CoutP + c * 8, ok);
-      *reinterpret_cast<U4*>(sY + p * 128 + ((c ^ (p & 7)) << 4)) = v;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr)(st + XB + (32 * u + 8 * wave) * 128), 16,
+                                               ok ? (unsigned)((((n * a.OH + oy) * a.OW + ox) * a.CoutP + c * 8) * 2) : OOB, 0, 0, 0);
     }
-    {
-      constexpr int NV = (HR * HC + 31) / 32;
-      U4 v[NV];
-#pragma unroll
-      for (int u = 0; u < NV; ++u) {
-        const int q = pbase + 32 * u;
-        const int hr = q / HC, hc = q - hr * HC;
-        const int iy = oy0 + hr + kh0 - a.pad, ix = ox0 + hc - a.pad;
-        const bool ok = xc_ok && q < HR * HC && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-        v[u] = load16_or_zero(X, ((size_t)(n * a.IH + iy) * a.IW + ix) * a.CinP + c * 8, ok);
-      }
-#pragma unroll
-      for (int u = 0; u < NV; ++u) {
-        const int q = pbase + 32 * u;
-        if (q < HR * HC) *reinterpret_cast<U4*>(sX + q * 128 + ((c ^ (q & 7)) << 4)) = v[u];
-      }
-    }
-    __syncthreads();
+  };
+
+  int t = blockIdx.z * a.tiles_per_block;
+  if (t < t_end) dma(t, 0);
+  int buf = 0;
+  for (; t < t_end; ++t, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // this tile landed; nobody still reads the other stage
+    asm volatile("" ::: "memory");
+    if (t + 1 < t_end) dma(t + 1, buf ^ 1);
+    const unsigned char* sX = smem + buf * STAGE;
+    const unsigned char* sY = sX + XB;
 #pragma unroll 1
     for (int r = 0; r < R; ++r) {
       U4 fa[CT];
