@@ -405,15 +405,21 @@ static void wgrad_plan(const dsr_conv_desc* d, WgradArgs& a) {
   a.fd_ow = fd_make((unsigned)OW);
 }
 
-static int tile_plan(const dsr_conv_desc* d, WgradTileArgs& t, bool* taps_kernel = nullptr) {
+static int tile_plan(const dsr_conv_desc* d, WgradTileArgs& t, bool* taps_kernel = nullptr, bool* toeplitz = nullptr) {
   int OH, OW;
   dsr_conv_out_size(d, &OH, &OW);
   memset(&t, 0, sizeof(t));
   int ych = dsr_wgrad_tile_plan(d->KH, d->KW, d->stride, d->N, OH, OW, r8(d->Cin), r8(d->Cout), &t);
   if (taps_kernel) *taps_kernel = false;
+  if (toeplitz) *toeplitz = false;
   if (ych == 0 && d->pad_mode == DSR_PAD_ZERO) {
-    ych = dsr_wgrad_taps_plan(d->KH, d->KW, d->stride, d->N, OH, OW, r8(d->Cin), r8(d->Cout), &t);
-    if (taps_kernel) *taps_kernel = ych > 0;
+    if (d->KH == 9 && d->KW == 9 && d->stride == 1 && d->pad == 4 && d->Cout <= 3 && r8(d->Cin) == 64) {
+      ych = dsr_wgrad_toeplitz_plan(d->N, d->H, d->W, &t);   // the generator's tail (generator.py:62)
+      if (toeplitz) *toeplitz = true;
+    } else {
+      ych = dsr_wgrad_taps_plan(d->KH, d->KW, d->stride, d->N, OH, OW, r8(d->Cin), r8(d->Cout), &t);
+      if (taps_kernel) *taps_kernel = ych > 0;
+    }
   }
   t.N = d->N;
   t.OH = OH;
@@ -448,13 +454,15 @@ extern "C" int dsr_conv_wgrad(const dsr_conv_desc* d, const void* x, const void*
   size_t need = dsr_conv_wgrad_workspace(d);
   if (!workspace || ws_bytes < need) return dsr_fail(DSR_E_WORKSPACE, "conv_wgrad: workspace %zu < %zu", ws_bytes, need);
   WgradTileArgs t;
-  bool taps_kernel = false;
-  int ych = tile_plan(d, t, &taps_kernel);
+  bool taps_kernel = false, toeplitz = false;
+  int ych = tile_plan(d, t, &taps_kernel, &toeplitz);
   if (ych > 0) {   // 3x3 (stride 1|2), 1x1, and 9x9 with few channels: taps derived from one staged halo tile
     t.x = x;
     t.dy = dy;
     t.partial = (float*)workspace;
-    if (taps_kernel)
+    if (toeplitz)
+      dsr_launch_wgrad_toeplitz(t, d->dtype, s);
+    else if (taps_kernel)
       dsr_launch_wgrad_taps(t, d->KH, ych, d->dtype, s);
     else
       dsr_launch_wgrad_tile(t, d->KH, d->stride, ych, d->dtype, s);
@@ -494,7 +502,8 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
   }
   WgradTileArgs t;
   bool taps = false;
-  int ych = tile_plan(d, t, &taps);
-  if (ych > 0) return taps ? "conv_wgrad_taps_kernel" : "conv_wgrad_tile_kernel";
+  bool toep = false;
+  int ych = tile_plan(d, t, &taps, &toep);
+  if (ych > 0) return toep ? "conv_wgrad_toeplitz9_kernel" : (taps ? "conv_wgrad_taps_kernel" : "conv_wgrad_tile_kernel");
   return "conv_wgrad_kernel";
 }

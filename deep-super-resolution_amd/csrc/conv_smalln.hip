@@ -504,6 +504,181 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(const WgradTile
 
 // returns the number of partial slabs, 0 if the shape is not handled (9x9, stride 1, one side <= 16 channels,
 // the other <= 64)
+// ------------------------------------------------------------------ 9x9 weight gradient, <= 3 output channels: Toeplitz rows
+// dW[kh][kw][co][ci] = sum_{y,x} dy[y][x][co] * in[y+kh-4][x+kw-4][ci].  With p = x + kw - 4 (input column) this is, for
+// every pair (input row r, tap row kh), one GEMM over the pixels p of the row:
+//     D_kh[(kw,co)][ci] += A_y[(kw,co)][p] * B_r[p][ci],   y = r - kh + 4,
+//     A_y[(kw,co)][p] = dy[y][p - kw + 4][co]   (27 rows: the dy row shifted once per kw),   B_r[p][ci] = in[r][p][ci].
+// All 9 kw share one MFMA row block instead of one MFMA each, and an input row is staged ONCE for its 9 tap rows
+// (the tap-per-MFMA kernel above re-stages it 7x and uses 3 of 16 MFMA rows).
+// A block walks the input rows of one (image, 64-column strip, row band): per row it DMAs B_r and the raw dy strip
+// of row r+6, builds A_{r+5} in LDS (a ring of 12 images), and its 3 waves (3 tap rows each) issue 48 MFMAs.
+// The pixel order inside an MFMA k-step is the permutation of the transposing read used for B
+// ({4g..4g+3} U {16+4g..16+4g+3} for lane group g); A is built in that same order.
+template <int DT>
+__global__ __launch_bounds__(192, 2) void conv_wgrad_toeplitz9_kernel(const WgradTileArgs a) {
+  constexpr int SLOTS = 12, A_IMG = 32 * 128, B_IMG = 64 * 128, D_RAW = 128 * 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SLOTS * A_IMG + 2 * B_IMG + 2 * D_RAW];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + SLOTS * A_IMG;
+  unsigned char* sD = sB + 2 * B_IMG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
+  // work item: image n, strip (64 input columns from p0), band of input rows [rb0, rb1)
+  const int strips = a.tiles_x, bands = a.tiles_y, rows_per_band = a.tiles_per_block;
+  const int item = blockIdx.x;
+  const int n = item / (strips * bands);
+  const int rem = item - n * strips * bands;
+  const int band = rem / strips, strip = rem - band * strips;
+  const int p0 = strip * 64;
+  const int rb0 = band * rows_per_band;
+  const int rb1 = rb0 + rows_per_band < a.IH ? rb0 + rows_per_band : a.IH;
+  const int H = a.IH, W = a.IW;
+
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  f32x4 acc[3][2][4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) acc[k][mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // DMA of input row r (64 pixels x 8 chunks = 8 wave-instructions: waves 0,1 issue 3, wave 2 issues 2) and of the raw
+  // dy strip of row yd (72 pixels x 16 B: one full and one mostly-masked wave-instruction, waves 0 and 1)
+  auto dma_rows = [&](int r, int yd) {
+    unsigned char* dstB = sB + (r & 1) * B_IMG;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int inst = wave + 3 * u;                     // wave-uniform
+      if (inst < 8) {
+        const int q = 8 * inst + (lane >> 3);            // pixel slot
+        const int ch = (lane & 7) ^ (q & 7);
+        const int ix = p0 + q;
+        const bool ok = (unsigned)r < (unsigned)H && ix < W;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(dstB + inst * 1024), 16,
+                                                 ok ? (unsigned)((((n * H + r) * W + ix) * 64 + ch * 8) * 2) : OOB, 0, 0, 0);
+      }
+    }
+    if (wave < 2) {
+      const int q = 64 * wave + lane;                    // raw slot: dy column p0 - 4 + q
+      const int x = p0 - 4 + q;
+      const bool ok = q < 72 && (unsigned)yd < (unsigned)H && (unsigned)x < (unsigned)W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr)(sD + (yd & 1) * D_RAW + wave * 1024), 16,
+                                               ok ? (unsigned)((((n * H + yd) * W + x) * 8) * 2) : OOB, 0, 0, 0);
+    }
+  };
+  // A_y from the raw strip: row m = 3kw + co, chunk pc = 4ks + gg holds pixels 32ks + {4gg..4gg+3, 16+4gg..16+4gg+3}
+  auto build_A = [&](int y) {
+    const unsigned char* raw = sD + (y & 1) * D_RAW;
+    unsigned char* img = sA + (((y % SLOTS) + SLOTS) % SLOTS) * A_IMG;
+    for (int idx = tid; idx < 256; idx += 192) {
+      const int m = idx >> 3, pc = idx & 7;
+      const int kw = m / 3, co = m - 3 * kw;
+      unsigned short e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int p = 32 * (pc >> 2) + (i < 4 ? 4 * (pc & 3) + i : 16 + 4 * (pc & 3) + (i - 4));
+        const int q = p - kw + 8;                        // raw slot of dy column p0 + p - kw + 4
+        e[i] = (m < 27) ? *reinterpret_cast<const unsigned short*>(raw + q * 16 + co * 2) : (unsigned short)0;
+      }
+      U4 v;
+      v.x = e[0] | ((unsigned)e[1] << 16);
+      v.y = e[2] | ((unsigned)e[3] << 16);
+      v.z = e[4] | ((unsigned)e[5] << 16);
+      v.w = e[6] | ((unsigned)e[7] << 16);
+      *reinterpret_cast<U4*>(img + m * 128 + ((pc ^ (m & 7)) << 4)) = v;
+    }
+  };
+
+  // rows rb0-9 .. rb0-1 only fill the ring (A_{rb0-4} .. A_{rb0+4}); from rb0 on every row also computes
+  const int r_start = rb0 - 9;
+  dma_rows(r_start, r_start + 5);
+  for (int r = r_start; r < rb1; ++r) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // B_r and raw dy(r+5) landed; A_{r+4} (built last step) is visible
+    asm volatile("" ::: "memory");
+    if (r + 1 < rb1) dma_rows(r + 1, r + 6);
+    build_A(r + 5);
+    if (r >= rb0) {
+      const unsigned char* bimg = sB + (r & 1) * B_IMG;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        U4 fb[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+          const int ch = nf * 16 + cc;
+          fb[nf] = tr_frag_sn(bimg, 32 * ks + 4 * g + q4, 32 * ks + 16 + 4 * g + q4, ch >> 3, (ch & 7) * 2);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int y = r - (3 * wave + k) + 4;
+          if ((unsigned)y < (unsigned)H) {               // wave-uniform
+            const unsigned char* img = sA + (y % SLOTS) * A_IMG;
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+              const int m = 16 * mf + l16;
+              const U4 fa = *reinterpret_cast<const U4*>(img + m * 128 + (((4 * ks + g) ^ (m & 7)) << 4));
+#pragma unroll
+              for (int nf = 0; nf < 4; ++nf) acc[k][mf][nf] = mfma16<DT>(fa, fb[nf], acc[k][mf][nf]);
+            }
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this step's LDS writes (A_{r+5}) are done before the barrier above
+  }
+
+  // D[m = 3kw + co][n = ci] -> partial[item][tap = 9kh + kw][co][ci]
+  float* P = a.partial + (size_t)item * 81 * 8 * 64;
+  for (int i = tid; i < 81 * 8 * 64 / 4; i += 192) reinterpret_cast<float4*>(P)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int kh = 3 * wave + k;
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = 16 * mf + 4 * g + j;
+        if (m < 27) {
+          const int kw = m / 3, co = m - 3 * kw;
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf)
+            P[((size_t)(kh * 9 + kw) * 8 + co) * 64 + 16 * nf + l16] = acc[k][mf][nf][j];
+        }
+      }
+  }
+}
+
+// plan: items = N x strips x bands (each writes one partial slab); returns the number of slabs
+int dsr_wgrad_toeplitz_plan(int N, int H, int W, WgradTileArgs* a) {
+  const int strips = (W + 63) / 64;
+  long long per = (long long)N * strips;
+  int bands = (int)(512 / per);
+  if (bands < 1) bands = 1;
+  const int maxb = (H + 31) / 32;
+  if (bands > maxb) bands = maxb;
+  a->tiles_x = strips;
+  a->tiles_y = bands;
+  a->tiles_per_block = (H + bands - 1) / bands;          // input rows per band
+  a->tiles_y = (H + a->tiles_per_block - 1) / a->tiles_per_block;
+  a->ntiles = N * strips * a->tiles_y;
+  a->tiles_co = a->tiles_ci = 1;
+  return a->ntiles;
+}
+
+void dsr_launch_wgrad_toeplitz(const WgradTileArgs& a, int dtype, hipStream_t st) {
+  if (dtype == DSR_DTYPE_BF16)
+    hipLaunchKernelGGL((conv_wgrad_toeplitz9_kernel<DSR_DTYPE_BF16>), dim3(a.ntiles), dim3(192), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad_toeplitz9_kernel<DSR_DTYPE_F16>), dim3(a.ntiles), dim3(192), 0, st, a);
+}
+
 int dsr_wgrad_taps_plan(int KH, int KW, int stride, int N, int OH, int OW, int CinP, int CoutP, WgradTileArgs* a) {
   if (!(KH == 9 && KW == 9 && stride == 1)) return 0;
   const bool small_out = CoutP <= 16 && CinP <= 64, small_in = CinP <= 16 && CoutP <= 64;

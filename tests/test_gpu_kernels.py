@@ -88,6 +88,7 @@ CONV_CASES = [
     ("dip_1x1_skip", 1, 32, 4, 12, 12, 1, 1, 0, 1, "none"),
     ("dip_1x1_128", 2, 128, 128, 8, 8, 1, 1, 0, 0, "leaky"),
     ("cout3_9x9", 1, 64, 3, 12, 12, 9, 1, 4, 0, "none"),
+    ("cout3_9x9_ragged", 2, 64, 3, 75, 140, 9, 1, 4, 0, "none"),    # Toeplitz fwd/wgrad: 3 strips (last ragged), 3 row bands
     ("vgg_3_64", 1, 3, 64, 14, 14, 3, 1, 1, 0, "relu"),
 ]
 
