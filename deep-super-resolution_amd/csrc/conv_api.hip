@@ -60,6 +60,10 @@ static bool is_cin8(const dsr_conv_desc* d, const dsr_epilogue* e) {   // first 
   return d->Cin <= 8 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
          d->pad_mode == DSR_PAD_ZERO && !(e && (e->stats_partial || e->pixel_shuffle || e->out_nchw_f32));
 }
+static bool is_tail9(const dsr_conv_desc* d) {
+  return d->KH == 9 && d->KW == 9 && d->stride == 1 && d->pad == 4 && d->pad_mode == DSR_PAD_ZERO && d->Cout <= 3 &&
+         r8(d->Cin) == 64;
+}
 static bool is_smalln_dgrad(const dsr_conv_desc* d) {
   return d->Cin <= 16 && r8(d->Cout) == 64 && d->stride == 1 && d->pad_mode == DSR_PAD_ZERO && d->KH == d->KW &&
          (d->KW == 3 || d->KW == 9) && 2 * d->pad == d->KH - 1;
@@ -299,6 +303,10 @@ extern "C" int dsr_conv_dgrad(const dsr_conv_desc* d, const void* dy, const void
     dsr_launch_conv_c64(c, d->N, d->dtype, s);
     return dsr_launch_status("dsr_conv_dgrad(c64)");
   }
+  if (is_tail9(d)) {   // the generator's 9x9 64->3 tail: Toeplitz K = (kw, co) mapping (conv_smalln.hip)
+    dsr_launch_dgrad_toeplitz(dy, w_dgrad, dx, d->N, d->H, d->W, d->dtype, s);
+    return dsr_launch_status("dsr_conv_dgrad(toeplitz)");
+  }
   if (is_smalln_dgrad(d)) {
     // few input channels (the RGB first layers, discriminator.py:22): dx = dy correlated with the mirrored kernel,
     // a stride-1 "forward" problem with Cin output channels -> the halo-staged small-N kernel
@@ -413,7 +421,7 @@ static int tile_plan(const dsr_conv_desc* d, WgradTileArgs& t, bool* taps_kernel
   if (taps_kernel) *taps_kernel = false;
   if (toeplitz) *toeplitz = false;
   if (ych == 0 && d->pad_mode == DSR_PAD_ZERO) {
-    if (d->KH == 9 && d->KW == 9 && d->stride == 1 && d->pad == 4 && d->Cout <= 3 && r8(d->Cin) == 64) {
+    if (is_tail9(d)) {
       ych = dsr_wgrad_toeplitz_plan(d->N, d->H, d->W, &t);   // the generator's tail (generator.py:62)
       if (toeplitz) *toeplitz = true;
     } else {
@@ -497,6 +505,7 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
   }
   if (op == 1) {
     if (is_c64(d)) return "conv_c64_kernel";
+    if (is_tail9(d)) return "conv_dgrad_toeplitz9_kernel";
     if (is_smalln_dgrad(d)) return "conv_smalln_kernel";
     return gemm_name(r8(d->Cin));
   }

@@ -7,6 +7,8 @@
 //                          one row per wave; weights [tap][16][Cin] stream from L1/L2 straight into B fragments.
 //  conv_wgrad_taps_kernel  weight gradient for KW-wide tap rows when Cout <= 16 or Cin <= 16: a block stages a
 //                          (R+KHB-1) x (31+KW) halo of X and an R x 32 tile of dY, its 4 waves split the KHB*KW taps.
+#include <string.h>
+
 #include "dsr_common.h"
 #include "dsr_kernels.h"
 
@@ -670,6 +672,163 @@ int dsr_wgrad_toeplitz_plan(int N, int H, int W, WgradTileArgs* a) {
   a->ntiles = N * strips * a->tiles_y;
   a->tiles_co = a->tiles_ci = 1;
   return a->ntiles;
+}
+
+// ------------------------------------------------------------------ 9x9 input gradient, <= 3 output channels: Toeplitz rows
+// dIn[r][p][ci] = sum_{kh,kw,co} dy[r-kh+4][p-kw+4][co] * W[kh][kw][co][ci]: with the same shifted image as above, stored
+// pixel-major ( A_y[p][k = 3kw + co] ), every (row r, tap row kh) is one MFMA K-step of 32 over k = (kw, co) -- 9 K-steps per
+// output row instead of the 21 of the tap-per-8-channels gather kernel (dy has 3 of 8 channels populated).
+// Weights (the [tap][ci][co] image) stay in registers for the life of the block as A' operands (m = ci), so the
+// accumulator holds 4 consecutive ci of one pixel and the 128-byte NHWC rows leave through a small per-wave LDS slab.
+struct Tail9DgradArgs {
+  const void* dy;   // [N][H][W][8]
+  const void* w;    // dgrad weight image [81][64][8]
+  void* dx;         // [N][H][W][64]
+  int N, H, W;
+  int strips, bands, rows_per_band;
+  unsigned dy_bytes;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv_dgrad_toeplitz9_kernel(const Tail9DgradArgs a) {
+  constexpr int SLOTS = 12, A_IMG = 64 * 64, D_RAW = 128 * 16, C_SLAB = 16 * 128;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SLOTS * A_IMG + 2 * D_RAW + 4 * C_SLAB];
+  unsigned char* sA = smem;
+  unsigned char* sD = smem + SLOTS * A_IMG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l16 = lane & 15;
+  unsigned char* sC = sD + 2 * D_RAW + wave * C_SLAB;
+  const int item = blockIdx.x;
+  const int n = item / (a.strips * a.bands);
+  const int rem = item - n * a.strips * a.bands;
+  const int band = rem / a.strips, strip = rem - band * a.strips;
+  const int p0 = strip * 64;
+  const int rb0 = band * a.rows_per_band;
+  const int rb1 = rb0 + a.rows_per_band < a.H ? rb0 + a.rows_per_band : a.H;
+  const int H = a.H, W = a.W;
+  const unsigned short* __restrict__ Wg = reinterpret_cast<const unsigned short*>(a.w);
+  unsigned short* __restrict__ DX = reinterpret_cast<unsigned short*>(a.dx);
+
+  // ---- weights -> registers: fw[kh][mf] = A'[m = ci 16mf + l16][k = 8g..8g+7], k = 3kw + co (k >= 27: zero)
+  U4 fw[9][4];
+#pragma unroll
+  for (int kh = 0; kh < 9; ++kh) {
+    __syncthreads();
+    for (int i = tid; i < 9 * 64; i += 256)              // slice [9 kw][64 ci][8 co] of this tap row -> LDS scratch (the ring area)
+      reinterpret_cast<U4*>(sA)[i] = reinterpret_cast<const U4*>(Wg)[kh * 9 * 64 + i];
+    __syncthreads();
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+      unsigned short e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 8 * g + i;
+        const int kw = k / 3, co = k - 3 * kw;
+        e[i] = k < 27 ? *reinterpret_cast<const unsigned short*>(sA + ((kw * 64 + 16 * mf + l16) * 8 + co) * 2) : (unsigned short)0;
+      }
+      fw[kh][mf].x = e[0] | ((unsigned)e[1] << 16);
+      fw[kh][mf].y = e[2] | ((unsigned)e[3] << 16);
+      fw[kh][mf].z = e[4] | ((unsigned)e[5] << 16);
+      fw[kh][mf].w = e[6] | ((unsigned)e[7] << 16);
+    }
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto dma_raw = [&](int yd) {                           // raw dy strip of row yd: columns p0-4 .. p0+67 (waves 0 and 1)
+    if (wave < 2) {
+      const int q = 64 * wave + lane;
+      const int x = p0 - 4 + q;
+      const bool ok = q < 72 && (unsigned)yd < (unsigned)H && (unsigned)x < (unsigned)W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr)(sD + (yd & 1) * D_RAW + wave * 1024), 16,
+                                               ok ? (unsigned)((((n * H + yd) * W + x) * 8) * 2) : OOB, 0, 0, 0);
+    }
+  };
+  auto build_A = [&](int y) {                            // A_y[p][k] = dy[y][p0 + p - kw + 4][co]; one 16-byte chunk per thread
+    const unsigned char* raw = sD + (y & 1) * D_RAW;
+    unsigned char* img = sA + (((y % SLOTS) + SLOTS) % SLOTS) * A_IMG;
+    const int p = tid >> 2, c = tid & 3;
+    unsigned short e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = 8 * c + i;
+      const int kw = k / 3, co = k - 3 * kw;
+      e[i] = k < 27 ? *reinterpret_cast<const unsigned short*>(raw + (p - kw + 8) * 16 + co * 2) : (unsigned short)0;
+    }
+    U4 v;
+    v.x = e[0] | ((unsigned)e[1] << 16);
+    v.y = e[2] | ((unsigned)e[3] << 16);
+    v.z = e[4] | ((unsigned)e[5] << 16);
+    v.w = e[6] | ((unsigned)e[7] << 16);
+    *reinterpret_cast<U4*>(img + p * 64 + ((c ^ ((p >> 2) & 3)) << 4)) = v;
+  };
+
+  const int px = 16 * wave + l16;                        // this lane's pixel (B' operand column) inside the strip
+  const int b_off = px * 64 + ((g ^ ((px >> 2) & 3)) << 4);
+  const int r_start = rb0 - 9;
+  dma_raw(r_start + 5);
+  for (int r = r_start; r < rb1; ++r) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (also drains the previous row's output stores)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (r + 1 < rb1) dma_raw(r + 6);
+    build_A(r + 5);
+    if (r >= rb0) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kh = 0; kh < 9; ++kh) {
+        const int y = r - kh + 4;
+        if ((unsigned)y < (unsigned)H) {                 // block-uniform
+          const U4 fb = *reinterpret_cast<const U4*>(sA + (y % SLOTS) * A_IMG + b_off);
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf) acc[mf] = mfma16<DT>(fw[kh][mf], fb, acc[mf]);
+        }
+      }
+      // acc[mf][j] = dIn[ci = 16mf + 4g + j][pixel l16 of this wave] -> slab -> 16-byte NHWC stores
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) {
+        uint2 h;
+        h.x = (unsigned)f2h<DT>(acc[mf][0]) | ((unsigned)f2h<DT>(acc[mf][1]) << 16);
+        h.y = (unsigned)f2h<DT>(acc[mf][2]) | ((unsigned)f2h<DT>(acc[mf][3]) << 16);
+        const int c16 = 2 * mf + (g >> 1);
+        *reinterpret_cast<uint2*>(sC + l16 * 128 + ((c16 ^ (l16 & 7)) << 4) + (g & 1) * 8) = h;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = lane + 64 * i;
+        const int pp = idx >> 3, c16 = idx & 7;
+        const U4 v = *reinterpret_cast<const U4*>(sC + pp * 128 + ((c16 ^ (pp & 7)) << 4));
+        const int x = p0 + 16 * wave + pp;
+        if (x < W) *reinterpret_cast<U4*>(DX + (((size_t)n * H + r) * W + x) * 64 + c16 * 8) = v;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+void dsr_launch_dgrad_toeplitz(const void* dy, const void* w_dgrad, void* dx, int N, int H, int W, int dtype, hipStream_t st) {
+  Tail9DgradArgs a;
+  a.dy = dy;
+  a.w = w_dgrad;
+  a.dx = dx;
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  WgradTileArgs t;
+  memset(&t, 0, sizeof(t));
+  dsr_wgrad_toeplitz_plan(N, H, W, &t);
+  a.strips = t.tiles_x;
+  a.bands = t.tiles_y;
+  a.rows_per_band = t.tiles_per_block;
+  a.dy_bytes = (unsigned)((size_t)N * H * W * 16);
+  if (dtype == DSR_DTYPE_BF16)
+    hipLaunchKernelGGL((conv_dgrad_toeplitz9_kernel<DSR_DTYPE_BF16>), dim3(t.ntiles), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_dgrad_toeplitz9_kernel<DSR_DTYPE_F16>), dim3(t.ntiles), dim3(256), 0, st, a);
 }
 
 void dsr_launch_wgrad_toeplitz(const WgradTileArgs& a, int dtype, hipStream_t st) {
