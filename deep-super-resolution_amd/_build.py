@@ -4,7 +4,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["conv_gemm.hip", "conv_gemm_persist.hip", "conv_wgrad.hip", "conv_wgrad_tile.hip", "conv_smalln.hip", "conv_c64.hip", "conv_cin8.hip", "conv_api.hip", "pointwise.hip", "linear.hip", "resample.hip"]
+SOURCES = ["conv_gemm.hip", "conv_gemm_persist.hip", "conv_wgrad.hip", "conv_wgrad_tile.hip", "conv_smalln.hip", "conv_c64.hip", "conv_cin8.hip", "conv_first_bwd.hip", "conv_api.hip", "pointwise.hip", "linear.hip", "resample.hip"]
 SO = os.path.join(CSRC, "libdsr_hip.so")
 
 

@@ -33,6 +33,9 @@ SIGNATURES = {
     "dsr_last_error": (C.c_char_p, []),
     "dsr_abi_version": (_I, []),
     "dsr_conv_kernel_name": (C.c_char_p, [_DESC, _I, C.POINTER(Epilogue)]),
+    "dsr_conv_first_bwd_supported": (_I, [_DESC, _I]),
+    "dsr_conv_first_bwd_workspace": (_Z, [_DESC]),
+    "dsr_conv_first_bwd": (_I, [_DESC, _P, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     "dsr_conv_out_size": (_I, [_DESC, C.POINTER(_I), C.POINTER(_I)]),
     "dsr_conv_stats_rows": (_I, [_DESC]),
     "dsr_conv_packed_elems": (_Z, [_DESC, _I]),

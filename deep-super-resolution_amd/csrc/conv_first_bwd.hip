@@ -1,0 +1,230 @@
+// Backward of a first layer whose input needs no gradient: Conv2d(<=3 -> 64, 3x3, stride 1, zero pad 1) + LeakyReLU /
+// ReLU / nothing (discriminator.py:22,25-27 on the HR-size images).  The reference computes, in three passes over
+// 64-channel tensors,  g = dout * act'(y);  db = sum_p g;  dW = sum_p g[p] x[p+tap]  (and no dx: the input is an image).
+// Here that is ONE pass: per tile the kernel
+//   * DMAs the dout and y tiles (128 pixels x 64 channels each) and the 4 x 66 pixel image halo into LDS,
+//   * rewrites the dout tile in place as g = dout * act'(y),
+//   * builds the im2col image B[p][col] with col = 3*tap + ci (27 columns), col 27 = 1.0 -- so that the GEMM
+//         D[co][col] = sum_p g[p][co] * B[p][col]         (pixels are the contraction index)
+//     yields dW in columns 0..26 and db in column 27,
+//   * issues 8 MFMAs per wave (both operands by transposing LDS reads, as in the other weight-gradient kernels).
+// It reads dout and y once (2 x 128 B per pixel) and nothing else of that size; the old path (act_bwd + colsum +
+// wgrad) moved 5 such tensors.  Deterministic: one partial [64][32] per block, folded by first_bwd_finalize_kernel.
+#include "../../include/dsr_hip.h"
+#include "dsr_common.h"
+#include "dsr_kernels.h"
+
+namespace {
+constexpr int FB_TR = 2, FB_TW = 64, FB_PX = FB_TR * FB_TW;          // 128 pixels per tile
+constexpr int FB_HC = FB_TW + 2, FB_HR = FB_TR + 2;                  // 66 x 4 halo
+constexpr int FB_T = FB_PX * 128;                                    // one 64-channel tile: 16 KB
+constexpr int FB_XRAW = 5 * 1024;                                    // 264 halo pixels x 16 B, rounded to whole DMA pieces
+constexpr int FB_B = FB_PX * 64;                                     // im2col image [128][32] bf16
+constexpr int FB_STAGE = 2 * FB_T + FB_XRAW;
+}   // namespace
+
+__device__ __forceinline__ s16x4 fb_tr_read(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv_first_bwd_kernel(const FirstBwdArgs a) {
+  // stage s: [dout tile | y tile | image halo]; the im2col image is built over the y tile once g has been formed
+  // (74 KB in all: two blocks per CU)
+  static_assert(FB_B <= FB_T, "im2col image must fit in the y tile");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FB_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dout), 0, a.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.y), 0, a.y_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int per_img = a.tiles_y * a.tiles_x;
+  const int chunk = (tid & 7) ^ ((tid >> 3) & 7);                    // source-side swizzle of the lane-linear 128-byte rows
+
+  auto dma = [&](int t, int buf) {
+    const int n = t / per_img;
+    const int rem = t - n * per_img;
+    const int ty = rem / a.tiles_x;
+    const int oy0 = ty * FB_TR, ox0 = (rem - ty * a.tiles_x) * FB_TW;
+    unsigned char* st = smem + buf * FB_STAGE;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                                    // 128 pixels x 8 chunks = 16 pieces per tensor, 4 per wave
+      const int p = 32 * u + 8 * wave + (lane >> 3);
+      const int oy = oy0 + (p >> 6), ox = ox0 + (p & 63);
+      const bool ok = oy < a.H && ox < a.W;
+      const unsigned off = ok ? (unsigned)((((n * a.H + oy) * a.W + ox) * 64 + chunk * 8) * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(drsrc, (lds_ptr)(st + (32 * u + 8 * wave) * 128), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr)(st + FB_T + (32 * u + 8 * wave) * 128), 16, off, 0, 0, 0);
+    }
+    {                                                                // halo: 264 pixels of 16 B = 5 pieces (waves 0..3 + wave 0 again)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int piece = wave + 4 * u;                              // wave-uniform
+        if (piece < 5) {
+          const int q = 64 * piece + lane;
+          const int hr = q / FB_HC, hc = q - hr * FB_HC;
+          const int iy = oy0 - 1 + hr, ix = ox0 - 1 + hc;
+          const bool ok = q < FB_HR * FB_HC && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(st + 2 * FB_T + piece * 1024), 16,
+                                                   ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * 8) * 2) : OOB, 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[2];
+  acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int t = blockIdx.x;
+  if (t < a.ntiles) dma(t, 0);
+  int buf = 0;
+  for (; t < a.ntiles; t += gridDim.x, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                    // this tile landed; the previous step's reads are done
+    asm volatile("" ::: "memory");
+    if (t + (int)gridDim.x < a.ntiles) dma(t + gridDim.x, buf ^ 1);
+    unsigned char* st = smem + buf * FB_STAGE;
+    // ---- g = dout * act'(y), in place (4 chunks per thread; slot (p, pos) holds channel chunk pos ^ (p & 7) in both tiles)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int off = (tid + 256 * u) * 16;
+      const U4 dv = *reinterpret_cast<const U4*>(st + off);
+      const U4 yv = *reinterpret_cast<const U4*>(st + FB_T + off);
+      float d[8], yy[8];
+      unpack8<DT>(dv, d);
+      unpack8<DT>(yv, yy);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d[i] *= act_grad_from_out(a.act, yy[i], a.slope);
+      *reinterpret_cast<U4*>(st + off) = pack8<DT>(d);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                    // every thread is done reading the y tile
+    asm volatile("" ::: "memory");
+    unsigned char* sBim = st + FB_T;
+    // ---- im2col image: row p (64 B), chunk c = 8 columns col = 3*tap + ci; col 27 = 1, 28..31 = 0
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + 256 * u;                                 // 128 pixels x 4 chunks
+      const int p = idx >> 2, c = idx & 3;
+      const int row = p >> 6, xx = p & 63;
+      const unsigned char* xr = st + 2 * FB_T;
+      unsigned short e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int col = 8 * c + i;
+        const int tap = col / 3, ci = col - 3 * tap;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        unsigned short v = 0;
+        if (col < 27) v = *reinterpret_cast<const unsigned short*>(xr + ((row + kh) * FB_HC + xx + kw) * 16 + ci * 2);
+        if (col == 27) v = f2h<DT>(1.f);
+        e[i] = v;
+      }
+      U4 v;
+      v.x = e[0] | ((unsigned)e[1] << 16);
+      v.y = e[2] | ((unsigned)e[3] << 16);
+      v.z = e[4] | ((unsigned)e[5] << 16);
+      v.w = e[6] | ((unsigned)e[7] << 16);
+      *reinterpret_cast<U4*>(sBim + p * 64 + ((c ^ ((p >> 1) & 3)) << 4)) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                    // g and the im2col image are complete
+    asm volatile("" ::: "memory");
+    // ---- D[co = 16*wave + ..][col] += sum over the tile's 128 pixels (4 K-steps of 32)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int p1 = 32 * ks + 4 * g + q4, p2 = p1 + 16;
+      U4 fa, fb[2];
+      {
+        const int ch = 16 * wave + cc;                               // A: g[p][co], co = 16*wave + (l16 after the transpose)
+        const s16x4 lo = fb_tr_read(st + p1 * 128 + (((ch >> 3) ^ (p1 & 7)) << 4) + (ch & 7) * 2);
+        const s16x4 hi = fb_tr_read(st + p2 * 128 + (((ch >> 3) ^ (p2 & 7)) << 4) + (ch & 7) * 2);
+        fa = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+        const int col = 16 * nf + cc;                                // B: im2col[p][col]
+        const s16x4 lo = fb_tr_read(sBim + p1 * 64 + (((col >> 3) ^ ((p1 >> 1) & 3)) << 4) + (col & 7) * 2);
+        const s16x4 hi = fb_tr_read(sBim + p2 * 64 + (((col >> 3) ^ ((p2 >> 1) & 3)) << 4) + (col & 7) * 2);
+        fb[nf] = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+      acc[0] = mfma16<DT>(fa, fb[0], acc[0]);
+      acc[1] = mfma16<DT>(fa, fb[1], acc[1]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  // partial[block][co][32]: lane (g, l16) holds D[co = 16*wave + 4g + j][col = 16nf + l16]
+  float* P = a.partial + (size_t)blockIdx.x * 64 * 32;
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) P[(16 * wave + 4 * g + j) * 32 + 16 * nf + l16] = acc[nf][j];
+}
+
+// dw[co][ci][tap] (OIHW, fp32) and db[co] from the per-block partials (fixed order: deterministic)
+__global__ void first_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int Cin, float* __restrict__ dw,
+                                          float* __restrict__ db) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;            // (co, col)
+  if (idx >= 64 * 32) return;
+  const int co = idx >> 5, col = idx & 31;
+  double s = 0.0;
+  int b = 0;
+  for (; b + 8 <= blocks; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + u) * 2048 + idx];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (double)v[u];
+  }
+  for (; b < blocks; ++b) s += (double)partial[(size_t)b * 2048 + idx];
+  if (col < 27) {
+    const int tap = col / 3, ci = col - 3 * tap;
+    if (ci < Cin) dw[((size_t)co * Cin + ci) * 9 + tap] = (float)s;
+  } else if (col == 27 && db != nullptr) {
+    db[co] = (float)s;
+  }
+}
+
+static int first_bwd_blocks(long long ntiles) { return (int)(ntiles < 512 ? ntiles : 512); }
+
+extern "C" size_t dsr_conv_first_bwd_workspace(const dsr_conv_desc* d) {
+  if (!d) return 0;
+  const long long ntiles = (long long)d->N * ((d->H + FB_TR - 1) / FB_TR) * ((d->W + FB_TW - 1) / FB_TW);
+  return (size_t)first_bwd_blocks(ntiles) * 64 * 32 * sizeof(float);
+}
+
+extern "C" int dsr_conv_first_bwd_supported(const dsr_conv_desc* d, int act) {
+  return d && d->Cin <= 3 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
+         d->pad_mode == DSR_PAD_ZERO && (act == DSR_ACT_NONE || act == DSR_ACT_LEAKY || act == DSR_ACT_RELU) &&
+         (size_t)d->N * d->H * d->W * 128 < (1ull << 31);
+}
+
+extern "C" int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const void* dout, const void* y, int act,
+                                  float slope, float* dw, float* db, void* workspace, size_t ws_bytes, dsr_stream_t s) {
+  if (!dsr_conv_first_bwd_supported(d, act)) return dsr_fail(DSR_E_UNSUPPORTED, "conv_first_bwd: unsupported layer");
+  if (!x || !dout || !y || !dw) return dsr_fail(DSR_E_ARG, "conv_first_bwd: null pointer");
+  const size_t need = dsr_conv_first_bwd_workspace(d);
+  if (!workspace || ws_bytes < need) return dsr_fail(DSR_E_WORKSPACE, "conv_first_bwd: workspace %zu < %zu", ws_bytes, need);
+  FirstBwdArgs a;
+  a.x = x;
+  a.dout = dout;
+  a.y = y;
+  a.partial = (float*)workspace;
+  a.N = d->N;
+  a.H = d->H;
+  a.W = d->W;
+  a.act = act;
+  a.slope = slope;
+  a.tiles_y = (d->H + FB_TR - 1) / FB_TR;
+  a.tiles_x = (d->W + FB_TW - 1) / FB_TW;
+  a.ntiles = d->N * a.tiles_y * a.tiles_x;
+  a.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * 16);
+  a.y_bytes = (unsigned)((size_t)d->N * d->H * d->W * 128);
+  const int blocks = first_bwd_blocks(a.ntiles);
+  if (d->dtype == DSR_BF16)
+    hipLaunchKernelGGL((conv_first_bwd_kernel<DSR_DTYPE_BF16>), dim3(blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_first_bwd_kernel<DSR_DTYPE_F16>), dim3(blocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(first_bwd_finalize_kernel, dim3(8), dim3(256), 0, s, (const float*)workspace, blocks, d->Cin, dw, db);
+  return dsr_launch_status("dsr_conv_first_bwd");
+}

@@ -142,6 +142,18 @@ struct Cin8Args {
 };
 void dsr_launch_conv_cin8(Cin8Args& a, int N, int dtype, hipStream_t st);
 
+// fused backward of a first layer (conv_first_bwd.hip)
+struct FirstBwdArgs {
+  const void* x;       // [N][H][W][8]
+  const void* dout;    // [N][H][W][64] gradient w.r.t. the activation output
+  const void* y;       // [N][H][W][64] activation output
+  float* partial;      // [blocks][64][32]
+  int N, H, W, act;
+  float slope;
+  int tiles_y, tiles_x, ntiles;
+  unsigned x_bytes, y_bytes;
+};
+
 void dsr_launch_wgrad_reduce(const float* partial, float* dw, int splits, int ntaps, int Cout, int Cin, int CoutP,
                              int CinP, hipStream_t st);
 

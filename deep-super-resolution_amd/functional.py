@@ -250,6 +250,18 @@ class ConvAct(torch.autograd.Function):
         oh, ow = _out_hw(desc)
         cyp = r8(cout)
         need_partial = ctx.has_bias or prelu is not None
+        if (not ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not ctx.ps and prelu is None
+                and lib.dsr_conv_first_bwd_supported(C.byref(desc), ctx.act)):
+            # first layer on an image (discriminator.py:22): activation mask, bias gradient and weight gradient in ONE
+            # pass over dout and y -- g = dout * act'(y) is never materialised
+            dw = torch.empty(ctx.wshape, dtype=torch.float32, device=x.device)
+            db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            wsz = lib.dsr_conv_first_bwd_workspace(C.byref(desc))
+            ws = torch.empty(wsz, dtype=torch.uint8, device=x.device)
+            check(_timed("wgrad", desc, lambda: lib.dsr_conv_first_bwd(
+                C.byref(desc), _ptr(x), _ptr(dout), _ptr(y), ctx.act, float(ctx.cfg.get("slope", 0.0)), _ptr(dw), _ptr(db),
+                _ptr(ws), wsz, _stream())))
+            return None, dw, db, None, None
         if ctx.act == ACT_NONE and not ctx.ps:
             dy = dout
             db = _colsum(dy, cout) if ctx.has_bias else None

@@ -82,6 +82,15 @@ size_t dsr_conv_wgrad_workspace(const dsr_conv_desc* d);
 int dsr_conv_wgrad(const dsr_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes,
                    dsr_stream_t s);
 
+/* Fused backward of a first layer whose input needs no gradient -- Conv2d(<=3 -> 64, 3x3, s1, p1) + LeakyReLU | ReLU |
+ * nothing (discriminator.py:22,25-27): dw (OIHW fp32) and db (nullable) from x, the gradient dout w.r.t. the activation
+ * output and that output y, in one pass (g = dout * act'(y) is never written).  _supported() says whether a descriptor
+ * qualifies; callers otherwise use dsr_pw_act_bwd + dsr_conv_wgrad. */
+int dsr_conv_first_bwd_supported(const dsr_conv_desc* d, int act);
+size_t dsr_conv_first_bwd_workspace(const dsr_conv_desc* d);
+int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const void* dout, const void* y, int act, float slope,
+                       float* dw, float* db, void* workspace, size_t ws_bytes, dsr_stream_t s);
+
 /* Which kernel the dispatcher launches for this descriptor (measurement aid: bench.py labels its HIP-event timings
  * with it so they can be matched against rocprofv3's kernel names).  op: 0 forward, 1 dgrad, 2 wgrad.  `e` may be
  * NULL (no statistics, no pixel shuffle, NHWC output).  Returns a static string; never NULL. */

@@ -412,3 +412,32 @@ def test_persistent_conv_equals_per_image_launches(dev, case):
     if dx_all is not None:
         assert torch.isfinite(dx_all.float()).all()
         assert torch.equal(dx_all, torch.cat(dxs))
+
+
+@pytest.mark.parametrize("n,h,w,actn", [(3, 37, 70, "leaky"), (2, 130, 200, "relu"), (1, 16, 24, "none"), (4, 64, 64, "leaky")])
+def test_first_layer_fused_backward(dev, n, h, w, actn):
+    """An image input needs no gradient (discriminator.py:22 on HR patches): ConvAct.backward then runs
+    dsr_conv_first_bwd -- activation mask + bias gradient + weight gradient in one pass.  It must match the fp32
+    reference and the unfused path (act_bwd + wgrad) that the same layer takes when its input does require grad."""
+    F = P("functional")
+    act = dict(none=F.ACT_NONE, leaky=F.ACT_LEAKY, relu=F.ACT_RELU)[actn]
+    x = bfr(filler.tensor(f"fl:x{h}", (n, 3, h, w)))
+    wt = bfr(filler.tensor(f"fl:w{h}", (64, 3, 3, 3), float(np.sqrt(3.0 / 27))))
+    b = filler.tensor(f"fl:b{h}", (64,), 0.1)
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = act_ref(F, TF.conv2d(x, wr, br, padding=1), act, 0.2)
+    probe = bfr(filler.tensor(f"fl:p{h}", tuple(yr.shape)))
+    (yr * probe).sum().backward()
+    cfg = dict(stride=1, pad=1, pad_mode=0, act=act, slope=0.2)
+    grads = []
+    for need_dx in (False, True):
+        xg = to_nhwc(x).to(dev).requires_grad_(need_dx)
+        wg, bg = wt.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        yg = F.ConvAct.apply(xg, wg, bg, None, cfg)
+        yg.backward(to_nhwc(probe, 64).to(dev))
+        torch.cuda.synchronize()
+        grads.append((wg.grad.cpu(), bg.grad.cpu()))
+    (dw_f, db_f), (dw_u, db_u) = grads
+    assert rel_err(dw_f, wr.grad) < 2.5e-2 and rel_err(db_f, br.grad) < 2.5e-2
+    # fused vs unfused: the fused kernel multiplies in fp32 and rounds g once, the unfused path stores g in bf16 first
+    assert rel_err(dw_f, dw_u) < 5e-3 and rel_err(db_f, db_u) < 5e-3
