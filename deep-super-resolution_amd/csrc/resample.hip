@@ -165,16 +165,42 @@ __global__ void resize_norm_fwd_kernel(const float* __restrict__ src, unsigned s
 #pragma unroll
   for (int k = 0; k < 8; ++k) o[k] = 0.f;
   const int y0 = ys[oy], ny = yc[oy], x0 = xs[ox], nx = xc[ox];
-  for (int c = 0; c < C && c < 3; ++c) {
-    const float* p = src + ((size_t)n * C + c) * H * W;
-    float acc = 0.f;
+  // the three channel planes share every address and weight; the x weights of this output column stay in registers
+  // (same summation order per channel as the plain triple loop: rows outer, columns inner)
+  constexpr int KX = 16;
+  float wxr[KX];
+#pragma unroll
+  for (int j = 0; j < KX; ++j) wxr[j] = j < nx ? xw[ox * KT + j] : 0.f;
+  const size_t plane = (size_t)H * W;
+  const float* p0 = src + (size_t)n * C * plane + (size_t)y0 * W + x0;
+  float acc[3] = {0.f, 0.f, 0.f};
+  if (nx <= KX) {
     for (int i = 0; i < ny; ++i) {
-      float row = 0.f;
-      for (int j = 0; j < nx; ++j) row += xw[ox * KT + j] * p[(size_t)(y0 + i) * W + x0 + j];
-      acc += yw[oy * KT + i] * row;
+      const float wyi = yw[oy * KT + i];
+      const float* r = p0 + (size_t)i * W;
+      float row[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < KX; ++j) {
+        if (j < nx) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            if (c < C) row[c] += wxr[j] * r[(size_t)c * plane + j];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] += wyi * row[c];
     }
-    o[c] = (acc - mean[c]) * istd[c];
+  } else {
+    for (int i = 0; i < ny; ++i) {
+      const float wyi = yw[oy * KT + i];
+      const float* r = p0 + (size_t)i * W;
+      float row[3] = {0.f, 0.f, 0.f};
+      for (int j = 0; j < nx; ++j)
+        for (int c = 0; c < 3 && c < C; ++c) row[c] += xw[ox * KT + j] * r[(size_t)c * plane + j];
+      for (int c = 0; c < 3; ++c) acc[c] += wyi * row[c];
+    }
   }
+  for (int c = 0; c < C && c < 3; ++c) o[c] = (acc[c] - mean[c]) * istd[c];
   *reinterpret_cast<U4*>(dst + pix * 8) = pack8<DT>(o);
 }
 
