@@ -120,6 +120,7 @@ def build_step(workload, dev, world):
     def step():
         return steps.gan_step(gen, disc, perc, opt_g, opt_d, lr, hr, sync_g, sync_d,
                               overlap=os.environ.get("DSR_GAN_OVERLAP", "1") != "0")[1]
+    step.modules = [gen, disc]
     return step, n * (s * f) ** 2
 
 
@@ -209,11 +210,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # DSR_DIST_REHEARSAL=1 (development aid, one-GPU box): every rank uses cuda:0 and the ranks talk over gloo, so the
+    # N > 1 code path (broadcast, gradient hooks, bucketed all-reduce, two-stream step) runs end to end without RCCL
+    rehearsal = os.environ.get("DSR_DIST_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     P("_lib").lib()
 
     step, px_per_rank = build_step(a.workload, dev, world)
@@ -243,6 +252,15 @@ def main():
         dt = float(t.item())
     ms = dt / a.steps * 1e3
     value = px_per_rank * world * a.steps / dt / 1e6
+    if rehearsal and world > 1 and hasattr(step, "modules"):
+        # every rank must hold bit-identical parameters after the same averaged updates
+        for m in step.modules:
+            cs = torch.stack([p.detach().double().abs().sum() for p in m.parameters()]).sum().reshape(1).cpu()
+            lo, hi = cs.clone(), cs.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert torch.isfinite(cs).all() and lo.item() == hi.item(), ("ranks diverged", lo.item(), hi.item())
+        note("rehearsal: parameters identical on all ranks")
 
     metric = {"infer_x8": "HR Mpixels/sec x8 generator inference", "dip_x2": "HR Mpixels/sec DIP iteration"}.get(
         a.workload, "HR Mpixels/sec x4 GAN train step")
