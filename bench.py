@@ -121,6 +121,9 @@ def build_step(workload, dev, world):
         return steps.gan_step(gen, disc, perc, opt_g, opt_d, lr, hr, sync_g, sync_d,
                               overlap=os.environ.get("DSR_GAN_OVERLAP", "1") != "0")[1]
     step.modules = [gen, disc]
+    # the roofline leg times kernels one at a time: on the single-stream form of the same step (identical launches,
+    # identical arithmetic) a launch's HIP-event bracket is not stretched by kernels of the other stream
+    step.serial = lambda: steps.gan_step(gen, disc, perc, opt_g, opt_d, lr, hr, sync_g, sync_d, overlap=False)[1]
     return step, n * (s * f) ** 2
 
 
@@ -275,7 +278,7 @@ def main():
         note("roofline leg")
         F = P("functional")
         F.KERNEL_LOG = []
-        step()
+        getattr(step, "serial", step)()
         torch.cuda.synchronize()
         fam = {}
         for kind, d, e0, e1, k in F.KERNEL_LOG:
@@ -292,6 +295,8 @@ def main():
                                "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
                                "traffic": pmc_traffic(a.workload, top),
                                "launches": cnt, "avg_launch_ms": t / cnt * 1e3,
+                               "measured_on": "single-stream form of the step (DSR_GAN_OVERLAP=0): per-kernel durations "
+                                              "are not stretched by the concurrent D/G halves of the timed step",
                                "families": {k: {"seconds": v[0], "tflops": v[1] / v[0] / 1e12, "launches": v[2]}
                                             for k, v in fam.items()}}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
