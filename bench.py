@@ -86,6 +86,8 @@ def build_step(workload, dev, world):
             lr_img = down(hr_img)
         z = (torch.rand(1, 32, hr_sz, hr_sz, generator=gcpu) * 0.1).to(dev)
         run = steps.DipRunner(net, down, z, lr_img, 0.01, 0.05)
+        if os.environ.get("DSR_HIP_GRAPH", "1") != "0":
+            return steps.GraphedStep(lambda: run.step()[0]), hr_sz * hr_sz
         return (lambda: run.step()[0]), hr_sz * hr_sz
     gen = Gm.Generator(cfg["factor"], 16).to(dev).train()
     n, s, f = cfg["batch"], cfg["lr"], cfg["factor"]
@@ -107,6 +109,9 @@ def build_step(workload, dev, world):
             sync_g()
             opt_g.step()
             return loss
+        if world == 1 and os.environ.get("DSR_HIP_GRAPH", "1") != "0":
+            # launch-bound workload (~500 launches per step): capture the whole step once, replay it per step
+            return steps.GraphedStep(step), n * (s * f) ** 2
         return step, n * (s * f) ** 2
     Dm, GANu = P("models.GAN.discriminator"), P("utils.GAN")
     F = P("functional")

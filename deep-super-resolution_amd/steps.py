@@ -94,6 +94,32 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
     return loss_d, loss_g, fake_det
 
 
+class GraphedStep:
+    """A whole step (forward, backward, fused Adam) captured once in a HIP graph and replayed.
+
+    The small workloads are launch-bound (config 2: ~500 kernel launches for 8 ms of work; a DIP iteration likewise), and
+    everything a step does is capturable by construction: the C ABI only enqueues on the given stream, never
+    allocates or synchronises, the Adam step counter and the BatchNorm batch counters live on the device, and
+    scratch comes from torch's allocator (graph-private pool during capture).  `fn` must read its inputs from fixed
+    tensors and return tensors; the returned tensors are the graph's static outputs (overwritten by each replay)."""
+
+    def __init__(self, fn, warmup=3):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                    # warm-up off the default stream, as graph capture requires
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fn()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out
+
+
 class DipRunner:
     """DIP.py:22-123 state: fixed noise input, jitter buffer, Lanczos downsampler, Adam over the net."""
 

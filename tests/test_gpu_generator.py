@@ -168,3 +168,30 @@ def test_tiled_inference_matches_whole_image(dev):
     ref = gan.generator_forward({k: v.clone() for k, v in sd.items()}, x.cpu(), False)
     assert (whole.cpu() - ref).abs().max().item() <= 0.02
     assert g.compute_dtype == torch.bfloat16                   # restored
+
+
+def test_graphed_step_equals_eager(dev):
+    """steps.GraphedStep (whole step captured in a HIP graph: forward, backward, weight re-packing, fused Adam with its
+    device-side step counter, BatchNorm running statistics) must leave exactly the state that the same number of
+    eager steps leaves."""
+    steps, optim = P("steps"), P("optim")
+    lr = filler.tensor("in:graph_lr", (2, 3, 16, 16), 0.5, 0.5).to(dev)
+    hr = filler.tensor("in:graph_hr", (2, 3, 64, 64)).to(dev)
+
+    def make():
+        g, _ = build(dev, 4, 2)
+        g.train()
+        opt = optim.FusedAdam(g.parameters(), lr=1e-3)
+        return g, (lambda: steps.gen_l1_step(g, opt, lr, hr)[0])
+
+    g_e, step_e = make()
+    for _ in range(5):
+        loss_e = step_e()
+    g_g, step_g = make()
+    graphed = steps.GraphedStep(step_g, warmup=2)         # 2 eager warm-up steps; capture itself executes nothing
+    for _ in range(3):
+        loss_g = graphed()
+    torch.cuda.synchronize()
+    assert torch.equal(loss_e, loss_g)
+    for (k, a), (_, b) in zip(g_e.state_dict().items(), g_g.state_dict().items()):
+        assert torch.equal(a, b), k

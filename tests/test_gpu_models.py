@@ -402,6 +402,37 @@ def test_dip_step_vs_oracle(dev):
         assert (out.cpu() - rout).abs().max().item() <= 3.0 * floor + 0.01, (it, floor)
 
 
+def test_dip_graphed_iteration_equals_eager(dev):
+    """A Deep-Image-Prior iteration (DIP.py:47-68 closure + Adam) replayed from a HIP graph leaves the same state as eager
+    iterations (reg_noise_std = 0 so that no random numbers are drawn; with noise the graph draws fresh noise per replay
+    from the registered generator, which has no eager twin to compare with bit for bit)."""
+    M, D, steps = P("models.DIP"), P("utils.downsampler"), P("steps")
+    kw = dict(skip_n33d=16, skip_n33u=16, skip_n11=4, num_scales=3)
+    sd = filler.fill_state_dict(gan.template(dip.skip_shapes(dip.SkipConfig(input_depth=8, **kw))))
+    down = D.Downsampler(3, 2, "lanczos2", phase=0.5, preserve_size=True).to(dev)
+    hr = filler.tensor("in:dg_hr", (1, 3, 32, 32), 0.5, 0.5)
+    lr_img = downsampler.downsampler_forward(hr, 2, "lanczos2", phase=0.5, preserve_size=True).to(dev)
+    zin = filler.tensor("in:dg_z", (1, 8, 32, 32), 0.05, 0.05)
+
+    def make():
+        net = M.get_net(8, "skip", "reflection", upsample_mode="bilinear", **kw)
+        net.load_state_dict(sd)
+        net.to(dev).train()
+        return net, steps.DipRunner(net, down, zin.to(dev), lr_img, 0.01, 0.0)
+
+    net_e, run_e = make()
+    for _ in range(4):
+        loss_e, out_e = run_e.step()
+    net_g, run_g = make()
+    graphed = steps.GraphedStep(run_g.step, warmup=2)
+    for _ in range(2):
+        loss_g, out_g = graphed()
+    torch.cuda.synchronize()
+    assert torch.equal(loss_e, loss_g) and torch.equal(out_e, out_g)
+    for (k, a), (_, b) in zip(net_e.state_dict().items(), net_g.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 def test_two_rank_gan_step_rehearsal(dev):
     """The N > 1 path end to end on the GPU: two ranks share cuda:0 and talk over gloo (RCCL cannot place two ranks
     on one device), running bench.py's config-3 step -- parameter broadcast, gradient hooks for the 2 GB dense1
