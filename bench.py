@@ -268,6 +268,7 @@ def main():
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             assert torch.isfinite(cs).all() and lo.item() == hi.item(), ("ranks diverged", lo.item(), hi.item())
+            note(f"rehearsal: checksum {type(m).__name__} {cs.item():.12e}")
         note("rehearsal: parameters identical on all ranks")
 
     metric = {"infer_x8": "HR Mpixels/sec x8 generator inference", "dip_x2": "HR Mpixels/sec DIP iteration"}.get(

@@ -73,6 +73,7 @@ SIGNATURES = {
     "dsr_linear_fwd": (_I, [_I, _P, _P, _P, _I, _F, _P, _I, _Z, _I, _P, _Z, _P]),
     "dsr_linear_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _Z, _P]),
     "dsr_linear_wgrad": (_I, [_I, _P, _P, _P, _I, _I, _Z, _P]),
+    "dsr_linear_wgrad_gathered": (_I, [_I, _P, _P, _P, _I, _I, _Z, _I, _F, _P]),
     "dsr_dense2_fwd": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "dsr_dense2_bwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "dsr_maxpool2_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),

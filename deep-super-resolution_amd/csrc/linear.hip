@@ -285,6 +285,56 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const unsigned short*
   }
 }
 
+// Data-parallel form: dW = scale * sum_r dyT_r xT_r over R gathered rank-local factor pairs ([R][O][BP], [R][K][BP]).
+// A data-parallel step would otherwise all-reduce dW itself (2.1 GB for the config-3 dense1; one xGMI link between two
+// GPUs moves that in ~30 ms) while the factors are 67 MB + 128 KB per rank: all-gather those and form the summed
+// gradient here.  The dyT fragments no longer fit in registers for R ranks, so they are re-read (L2) per k tile.
+template <int DT, int BP>
+__global__ __launch_bounds__(256) void linear_wgrad_gathered_kernel(const unsigned short* __restrict__ dyT,
+                                                                    const unsigned short* __restrict__ xT,
+                                                                    float* __restrict__ dw, int O, size_t K, int R,
+                                                                    float scale, int ktiles_per_block) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hf = lane >> 5;
+  const int o0 = blockIdx.y * 256 + wave * 64;
+  if (o0 >= O) return;
+  constexpr int KS = BP / 16;
+  const size_t kt0 = (size_t)blockIdx.x * ktiles_per_block;
+  for (int t = 0; t < ktiles_per_block; ++t) {
+    const size_t kbase = (kt0 + t) * 32;
+    if (kbase >= K) break;
+    const size_t krow = kbase + r;
+    f32x16 acc[2];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mf][i] = 0.f;
+    for (int q = 0; q < R; ++q) {
+      U4 fb[KS], fa[2][KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) fb[s] = load16_or_zero(xT, ((size_t)q * K + krow) * BP + 16 * s + 8 * hf, krow < K);
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) {
+        const int o = o0 + 32 * mf + r;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) fa[mf][s] = load16_or_zero(dyT, ((size_t)q * O + o) * BP + 16 * s + 8 * hf, o < O);
+      }
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc[mf] = mfma32<DT>(fa[mf][s], fb[s], acc[mf]);
+    }
+    const size_t k = kbase + r;
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int o = o0 + 32 * mf + 8 * (i >> 2) + 4 * hf + (i & 3);
+        if (o < O && k < K) dw[(size_t)o * K + k] = acc[mf][i] * scale;
+      }
+  }
+}
+
 // ------------------------------------------------------------------ the small fp32 tail: Linear(K1,1) + Sigmoid and its backward
 // out[b] = sigmoid(sum_k h[b][k] w2[k] + b2)
 __global__ __launch_bounds__(256) void dense2_fwd_kernel(const float* __restrict__ h, const float* __restrict__ w2,
@@ -438,6 +488,26 @@ extern "C" int dsr_linear_wgrad(int dtype, const void* dyT16, const void* xT16, 
   }
 #undef LAUNCH_WG
   return dsr_launch_status("dsr_linear_wgrad");
+}
+
+extern "C" int dsr_linear_wgrad_gathered(int dtype, const void* dyT16_all, const void* xT16_all, float* dw, int Bp, int O,
+                                         size_t K, int R, float scale, dsr_stream_t st) {
+  if (Bp != 32 && Bp != 64) return dsr_fail(DSR_E_UNSUPPORTED, "linear_wgrad_gathered: padded batch must be 32 or 64");
+  if (R < 1) return dsr_fail(DSR_E_ARG, "linear_wgrad_gathered: R < 1");
+  const int tpb = 16;
+  size_t ktiles = (K + 31) / 32;
+  dim3 grid((unsigned)((ktiles + tpb - 1) / tpb), (O + 255) / 256), block(256);
+  const unsigned short* DYT = (const unsigned short*)dyT16_all;
+  const unsigned short* XT = (const unsigned short*)xT16_all;
+#define LAUNCH_WGG(DTV, BPV) \
+  hipLaunchKernelGGL((linear_wgrad_gathered_kernel<DTV, BPV>), grid, block, 0, st, DYT, XT, dw, O, K, R, scale, tpb)
+  if (dtype == DSR_BF16) {
+    if (Bp == 32) LAUNCH_WGG(DSR_DTYPE_BF16, 32); else LAUNCH_WGG(DSR_DTYPE_BF16, 64);
+  } else {
+    if (Bp == 32) LAUNCH_WGG(DSR_DTYPE_F16, 32); else LAUNCH_WGG(DSR_DTYPE_F16, 64);
+  }
+#undef LAUNCH_WGG
+  return dsr_launch_status("dsr_linear_wgrad_gathered");
 }
 
 extern "C" int dsr_dense2_fwd(const float* h, const float* w2, const float* b2, int B, int K1, float* out,

@@ -6,10 +6,13 @@ strategy.  Semantics: every rank runs train_GAN.py:38-71 on its own shard of the
 (per-rank) BatchNorm statistics; after each backward the parameter gradients are averaged, so every rank applies
 the same Adam update (mean-reduced losses over equal shards average exactly to the global-batch loss).
 
-Bucketing follows the hardware: xGMI is point-to-point, so few large messages beat many small ones.  Tensors of
-at least ``big_bytes`` (the discriminator's dense1.weight gradient is 2.1 GB at 512x512) are reduced in place,
-each as its own message, in the order autograd produced them; everything smaller is packed into flat buckets of
-``bucket_bytes``.  Collectives are issued asynchronously and only waited for right before the optimiser.
+Bucketing follows the hardware: xGMI is point-to-point, so few large messages beat many small ones, and the one huge
+gradient is not exchanged at all: the discriminator's dense1.weight gradient is 2.1 GB at 512x512 (a single xGMI link
+between two GPUs would need ~30 ms for its all-reduce), but it is the product of two small rank-local factors
+(dy^T: 128 KB, x^T: 67 MB).  functional.DenseHead all-gathers those and forms the rank-averaged gradient itself
+(``dsr_linear_wgrad_gathered``); this module marks the tensor and skips it.  Other tensors of at least ``big_bytes``
+are reduced in place, each as its own message, from autograd's post-accumulate hook; everything smaller is packed into
+flat buckets of ``bucket_bytes``.  Collectives are issued asynchronously and only waited for right before the optimiser.
 """
 import torch
 import torch.distributed as dist
@@ -45,12 +48,21 @@ class GradSync:
         self._early = set()
         self._hooks = []
 
-    def attach(self):
+    def attach(self, factor_gather=True):
+        """``factor_gather``: 2-D parameters of at least ``big_bytes`` (the dense head's K x 1024 matrix) are marked
+        ``_dsr_grad_global``: functional.DenseHead then all-gathers the small rank-local factors of that gradient and
+        forms the rank-averaged gradient itself, and this object leaves the tensor alone.  Anything else that big is
+        all-reduced from its post-accumulate hook."""
         if not is_dist() or self._hooks:
             return self
+        import os
+        factor_gather = factor_gather and os.environ.get("DSR_DP_FACTOR_GATHER", "1") != "0"   # 0: plain all-reduce
         for p in self.params:
             if p.numel() * p.element_size() >= self.big_bytes:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+                if factor_gather and p.dim() == 2 and getattr(p, "_dsr_dense_head", False):
+                    p._dsr_grad_global = True
+                else:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
         return self
 
     def _on_grad_ready(self, p):
@@ -68,7 +80,7 @@ class GradSync:
         small, size = [], 0
         for p in reversed(self.params):          # reverse registration order ~ order grads became ready
             g = p.grad
-            if g is None or id(p) in self._early:
+            if g is None or id(p) in self._early or getattr(p, "_dsr_grad_global", False):
                 continue
             nbytes = g.numel() * g.element_size()
             if nbytes >= self.big_bytes:

@@ -48,6 +48,7 @@ class Discriminator(nn.Module):
                                           DiscriminatorConvBlock(in_channels=512, out_channels=512, stride=2)])
         dense1_shape = self.fc_input_shape(HR_image_shape)
         self.dense1 = nn.Linear(in_features=dense1_shape, out_features=1024)
+        self.dense1.weight._dsr_dense_head = True    # dist.GradSync: gather this gradient's factors instead of reducing it
         self.leakyrelu2 = nn.LeakyReLU(negative_slope=0.2)
         self.dense2 = nn.Linear(1024, 1)
         self.sigmoid = nn.Sigmoid()

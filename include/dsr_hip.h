@@ -168,6 +168,10 @@ int dsr_linear_dgrad(int dtype, const void* dy16, const void* w16, void* dx, int
 /* dw[o][k] (fp32, overwritten) = sum_b dyT16[o][b] xT16[k][b];  Bp in {32, 64} */
 int dsr_linear_wgrad(int dtype, const void* dyT16, const void* xT16, float* dw, int Bp, int O, size_t K,
                      dsr_stream_t s);
+/* data-parallel form: dw = scale * sum over R gathered rank-local factor pairs, dyT16_all [R][O][Bp], xT16_all [R][K][Bp]
+ * (all-gather the 67 MB + 128 KB factors instead of all-reducing the 2.1 GB gradient) */
+int dsr_linear_wgrad_gathered(int dtype, const void* dyT16_all, const void* xT16_all, float* dw, int Bp, int O, size_t K,
+                              int R, float scale, dsr_stream_t s);
 /* out[b] = sigmoid(h[b][:] . w2 + b2) */
 int dsr_dense2_fwd(const float* h, const float* w2, const float* b2, int B, int K1, float* out, dsr_stream_t s);
 /* backward of the fp32 tail; also emits the 16-bit dy / dy^T operands of the two dense1 GEMMs */

@@ -119,6 +119,31 @@ def test_linear_kernels_ragged(dev, dtype, b, k, o):
     assert (dw.cpu().double() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
 
 
+def test_linear_wgrad_gathered(dev):
+    """dsr_linear_wgrad_gathered (data-parallel dense head: summed gradient from all-gathered rank-local factors) equals
+    the mean of the per-rank dsr_linear_wgrad results."""
+    import ctypes as C
+    L = P("_lib")
+    lib = L.lib()
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    R, o, k, bp = 3, 200, 1160, 64
+    dyt = (torch.rand(R, o, bp, device=dev) - 0.5).to(torch.bfloat16)
+    xt = (torch.rand(R, k, bp, device=dev) - 0.5).to(torch.bfloat16)
+    dw = torch.full((o, k), float("nan"), dtype=torch.float32, device=dev)
+    L.check(lib.dsr_linear_wgrad_gathered(0, ptr(dyt), ptr(xt), ptr(dw), bp, o, k, R, 1.0 / R, st))
+    ref = torch.zeros((o, k), dtype=torch.float64, device=dev)
+    for r in range(R):
+        one = torch.empty((o, k), dtype=torch.float32, device=dev)
+        L.check(lib.dsr_linear_wgrad(0, ptr(dyt[r]), ptr(xt[r]), ptr(one), bp, o, k, st))
+        ref += one.double()
+    ref /= R
+    torch.cuda.synchronize()
+    assert (dw.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    exact = (dyt.double().permute(1, 0, 2).reshape(o, R * bp) @ xt.double().permute(1, 0, 2).reshape(k, R * bp).t()) / R
+    assert (dw.double() - exact).abs().max().item() <= 1e-5 * max(1.0, exact.abs().max().item())
+
+
 def test_maxpool_bilinear_concat(dev):
     F = P("functional")
     x = bfr(filler.tensor("mp:x", (2, 16, 6, 10)))
@@ -436,8 +461,9 @@ def test_dip_graphed_iteration_equals_eager(dev):
 def test_two_rank_gan_step_rehearsal(dev):
     """The N > 1 path end to end on the GPU: two ranks share cuda:0 and talk over gloo (RCCL cannot place two ranks
     on one device), running bench.py's config-3 step -- parameter broadcast, gradient hooks for the 2 GB dense1
-    gradient, bucketed all-reduce, the two-stream D/G overlap.  bench.py itself asserts that both ranks hold
-    bit-identical parameters after the averaged updates."""
+    gradient (all-gathered rank-local factors + dsr_linear_wgrad_gathered, and the plain all-reduce it replaces),
+    bucketed all-reduce, the two-stream D/G overlap.  bench.py itself asserts that both ranks hold bit-identical
+    parameters after the averaged updates; here the two exchange forms must also agree with each other."""
     import os
     import subprocess
     import sys
@@ -446,10 +472,16 @@ def test_two_rank_gan_step_rehearsal(dev):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
            "--no-cpu-baseline", "--no-roofline"]
-    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert "rehearsal: parameters identical on all ranks" in r.stderr
     import json
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["value"] > 0
+    import re
+    sums = {}
+    for mode in ("1", "0"):      # dense1 gradient by all-gathered factors (default) | by plain all-reduce
+        r = subprocess.run(cmd, cwd=root, env=dict(env, DSR_DP_FACTOR_GATHER=mode), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "rehearsal: parameters identical on all ranks" in r.stderr
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert out["n_gpus"] == 2 and out["value"] > 0
+        sums[mode] = {m.group(1): float(m.group(2)) for m in re.finditer(r"checksum (\w+) ([0-9.e+-]+)", r.stderr)}
+    # both exchanges produce the same averaged update (they differ only in fp32 summation order)
+    for name, v in sums["1"].items():
+        assert abs(v - sums["0"][name]) <= 1e-6 * abs(v), (name, v, sums["0"][name])
