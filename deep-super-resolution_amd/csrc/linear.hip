@@ -29,29 +29,71 @@ __global__ void cast16_kernel(const float* __restrict__ src, unsigned short* __r
 // mode 0: flat[b][c*HW+p] = act[b][p][c]        (forward input of dense1)
 // mode 1: flatT[c*HW+p][b] = act[b][p][c]       (batch-minor copy for wgrad; Bp columns, zero padded)
 // mode 2: act[b][p][c] = flat[b][c*HW+p]        (gradient back to NHWC)
+// All three are 2-byte transposes; a thread moves 8 channels (one 16-byte NHWC vector) and the 64 lanes of a wave sit
+// on the index that is CONTIGUOUS ON THE 2-BYTE SIDE (pixels for modes 0/2, batch for mode 1), so every 2-byte-side
+// access is one 128-byte line per wave; the 16-byte side is strided, but a wave walks the 8 vectors of each 128-byte
+// line back to back (L1 hits).  The element-per-thread form touched one line per 2 bytes.
 template <int DT>
-__global__ void flatten_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst, int B, int HW,
-                               int C, int Cp, int Bp, int mode) {
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t K = (size_t)C * HW;
-  if (mode == 0) {
-    if (idx >= (size_t)B * K) return;
-    int b = (int)(idx / K);
-    size_t k = idx % K;
-    int c = (int)(k / HW), p = (int)(k % HW);
-    dst[idx] = src[((size_t)b * HW + p) * Cp + c];
-  } else if (mode == 1) {
-    if (idx >= K * Bp) return;
-    int b = (int)(idx % Bp);
-    size_t k = idx / Bp;
-    int c = (int)(k / HW), p = (int)(k % HW);
-    dst[idx] = b < B ? src[((size_t)b * HW + p) * Cp + c] : (unsigned short)0;
-  } else {
-    if (idx >= (size_t)B * HW * Cp) return;
-    int c = (int)(idx % Cp);
-    size_t bp = idx / Cp;
-    int p = (int)(bp % HW), b = (int)(bp / HW);
-    dst[idx] = c < C ? src[(size_t)b * K + (size_t)c * HW + p] : (unsigned short)0;
+__global__ __launch_bounds__(256) void flatten_kernel(const unsigned short* __restrict__ src,
+                                                      unsigned short* __restrict__ dst, int B, int HW, int C, int Cp,
+                                                      int Bp, int mode) {
+  const int lane = threadIdx.x & 63;
+  const size_t wv = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per (64 items, 64-channel group)
+  const int cgroups = (Cp + 63) / 64;
+  if (mode == 0 || mode == 2) {
+    const int ptiles = (HW + 63) / 64;
+    if (wv >= (size_t)B * ptiles * cgroups) return;
+    const int cg = (int)(wv % cgroups);
+    const int pt = (int)((wv / cgroups) % ptiles);
+    const int b = (int)(wv / ((size_t)cgroups * ptiles));
+    const int p = pt * 64 + lane;
+    if (p >= HW) return;
+    const size_t K = (size_t)C * HW;
+    for (int c8 = 0; c8 < 8; ++c8) {
+      const int c0 = cg * 64 + c8 * 8;
+      if (c0 >= Cp) break;
+      if (mode == 0) {                                   // flat[b][c*HW+p] = act[b][p][c]
+        const U4 v = *reinterpret_cast<const U4*>(src + ((size_t)b * HW + p) * Cp + c0);
+        const unsigned short e[8] = {(unsigned short)(v.x & 0xffff), (unsigned short)(v.x >> 16),
+                                     (unsigned short)(v.y & 0xffff), (unsigned short)(v.y >> 16),
+                                     (unsigned short)(v.z & 0xffff), (unsigned short)(v.z >> 16),
+                                     (unsigned short)(v.w & 0xffff), (unsigned short)(v.w >> 16)};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (c0 + i < C) dst[(size_t)b * K + (size_t)(c0 + i) * HW + p] = e[i];
+      } else {                                           // act[b][p][c] = flat[b][c*HW+p]  (pad channels zero)
+        unsigned short e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = (c0 + i < C) ? src[(size_t)b * K + (size_t)(c0 + i) * HW + p] : (unsigned short)0;
+        U4 v;
+        v.x = e[0] | ((unsigned)e[1] << 16);
+        v.y = e[2] | ((unsigned)e[3] << 16);
+        v.z = e[4] | ((unsigned)e[5] << 16);
+        v.w = e[6] | ((unsigned)e[7] << 16);
+        *reinterpret_cast<U4*>(dst + ((size_t)b * HW + p) * Cp + c0) = v;
+      }
+    }
+  } else {                                               // mode 1: flatT[c*HW+p][b] = act[b][p][c]  (Bp columns, zero padded)
+    const int btiles = (Bp + 63) / 64;
+    if (wv >= (size_t)HW * btiles * cgroups) return;
+    const int cg = (int)(wv % cgroups);
+    const int bt = (int)((wv / cgroups) % btiles);
+    const int p = (int)(wv / ((size_t)cgroups * btiles));
+    const int b = bt * 64 + lane;
+    if (b >= Bp) return;
+    for (int c8 = 0; c8 < 8; ++c8) {
+      const int c0 = cg * 64 + c8 * 8;
+      if (c0 >= Cp) break;
+      U4 v = U4{0u, 0u, 0u, 0u};
+      if (b < B) v = *reinterpret_cast<const U4*>(src + ((size_t)b * HW + p) * Cp + c0);
+      const unsigned short e[8] = {(unsigned short)(v.x & 0xffff), (unsigned short)(v.x >> 16),
+                                   (unsigned short)(v.y & 0xffff), (unsigned short)(v.y >> 16),
+                                   (unsigned short)(v.z & 0xffff), (unsigned short)(v.z >> 16),
+                                   (unsigned short)(v.w & 0xffff), (unsigned short)(v.w >> 16)};
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (c0 + i < C) dst[((size_t)(c0 + i) * HW + p) * Bp + b] = e[i];
+    }
   }
 }
 
@@ -401,8 +443,10 @@ extern "C" int dsr_cast16(int dtype, const float* src, void* dst, size_t n, dsr_
 
 extern "C" int dsr_flatten(int dtype, const void* src, void* dst, int B, int HW, int C, int Cp, int Bp, int mode,
                            dsr_stream_t st) {
-  size_t total = mode == 0 ? (size_t)B * C * HW : (mode == 1 ? (size_t)C * HW * Bp : (size_t)B * HW * Cp);
-  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (Cp % 8) return dsr_fail(DSR_E_ARG, "flatten: Cp %% 8 != 0");
+  const size_t cgroups = (size_t)(Cp + 63) / 64;
+  const size_t waves = mode == 1 ? (size_t)HW * ((Bp + 63) / 64) * cgroups : (size_t)B * ((HW + 63) / 64) * cgroups;
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   if (dtype == DSR_BF16)
     hipLaunchKernelGGL((flatten_kernel<DSR_DTYPE_BF16>), grid, block, 0, st, (const unsigned short*)src,
                        (unsigned short*)dst, B, HW, C, Cp, Bp, mode);
