@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "../../include/dsr_hip.h"
 #include "dsr_common.h"
 #include "dsr_kernels.h"
@@ -64,6 +66,14 @@ static bool is_tail9(const dsr_conv_desc* d) {
   return d->KH == 9 && d->KW == 9 && d->stride == 1 && d->pad == 4 && d->pad_mode == DSR_PAD_ZERO && d->Cout <= 3 &&
          r8(d->Cin) == 64;
 }
+// Cin = 64 forward convs with Cout a multiple of 64 (PixelShuffle convs 64->256, D's 64->128, VGG 64->128): their K
+// loop is 9 steps, where the gather kernel's per-tile prologue/epilogue costs as much as the loop; the weights-in-
+// registers kernel runs one 64-channel output slice per block row instead
+static bool is_c64_wide(const dsr_conv_desc* d) {
+  static const bool on = [] { const char* e = getenv("DSR_C64_WIDE"); return !(e && e[0] == '0'); }();
+  return on && d->Cin == 64 && d->Cout > 64 && d->Cout % 64 == 0 && d->Cout <= 256 && d->KH == 3 && d->KW == 3 &&
+         d->stride == 1 && d->pad == 1 && d->pad_mode == DSR_PAD_ZERO;
+}
 static bool is_smalln_dgrad(const dsr_conv_desc* d) {
   return d->Cin <= 16 && r8(d->Cout) == 64 && d->stride == 1 && d->pad_mode == DSR_PAD_ZERO && d->KH == d->KW &&
          (d->KW == 3 || d->KW == 9) && 2 * d->pad == d->KH - 1;
@@ -76,7 +86,7 @@ static bool is_c64(const dsr_conv_desc* d) {
 extern "C" int dsr_conv_stats_rows(const dsr_conv_desc* d) {
   int OH, OW;
   if (dsr_conv_out_size(d, &OH, &OW)) return -1;
-  if (is_c64(d)) return dsr_c64_tiles(d->N, OH, OW);      // the trunk kernel writes one statistics row per spatial tile
+  if (is_c64(d) || is_c64_wide(d)) return dsr_c64_tiles(d->N, OH, OW);   // one statistics row per spatial tile
   long long M = (long long)d->N * OH * OW;
   return (int)((M + 127) / 128);
 }
@@ -156,9 +166,10 @@ extern "C" int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w
     a.OW = OW;
     a.CoutP = r8(d->Cout);
   }
-  if (is_c64(d) && !e->pixel_shuffle && !e->out_nchw_f32) {
+  if (((is_c64(d) && !e->pixel_shuffle) || is_c64_wide(d)) && !e->out_nchw_f32) {
     C64Args c;
     memset(&c, 0, sizeof(c));
+    c.CoutP = d->Cout;
     c.x = x;
     c.w = w_fwd;
     c.y = y;
@@ -289,6 +300,7 @@ extern "C" int dsr_conv_dgrad(const dsr_conv_desc* d, const void* dy, const void
   if (is_c64(d)) {   // mirrored taps on the [tap][ci][co] weight image
     C64Args c;
     memset(&c, 0, sizeof(c));
+    c.CoutP = 64;
     c.x = dy;
     c.w = w_dgrad;
     c.y = dx;
@@ -496,7 +508,7 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
   if (!d || check_desc(d)) return "invalid";
   const bool ps = e && e->pixel_shuffle, nchw = e && e->out_nchw_f32, stats = e && e->stats_partial;
   if (op == 0) {
-    if (is_c64(d) && !ps && !nchw) return "conv_c64_kernel";
+    if (((is_c64(d) && !ps) || is_c64_wide(d)) && !nchw) return "conv_c64_kernel";
     if (is_cin8(d, e)) return "conv_cin8_kernel";
     if (d->Cout <= 16 && d->stride == 1 && d->pad_mode == DSR_PAD_ZERO && d->KH * d->KW >= 9 && !stats && !ps &&
         d->KW == 9 && d->KH <= 9 && r8(d->Cin) == 64)

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
   const int wp = wave >> 1, wc = wave & 1;     // tile row, channel half (32 co)
+  const int c0 = blockIdx.y * 64;              // this block's slice of the output channels (Cout = 64 * gridDim.y)
   const unsigned short* __restrict__ X = reinterpret_cast<const unsigned short*>(a.x);
   const unsigned short* __restrict__ W = reinterpret_cast<const unsigned short*>(a.w);
   unsigned short* __restrict__ Y = reinterpret_cast<unsigned short*>(a.y);
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
-        fw[t][kk][nt] = *reinterpret_cast<const U4*>(W + ((size_t)(t * 64 + wc * 32 + nt * 16 + r16)) * 64 + kk * 32 + g * 8);
+        fw[t][kk][nt] = *reinterpret_cast<const U4*>(W + ((size_t)(t * a.CoutP + c0 + wc * 32 + nt * 16 + r16)) * 64 + kk * 32 + g * 8);
 
   // A-fragment LDS offsets: pixel column (tx + r16) -> (tx + r16)*128 + swizzled chunk; + row*HC*128 + hx*2048
   int lds_off[3][2];
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   const bool do_stats = (a.flags & DSR_F_STATS) != 0;
   float bias_v[2];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) bias_v[nt] = (a.flags & DSR_F_BIAS) ? a.bias[wc * 32 + nt * 16 + r16] : 0.f;
+  for (int nt = 0; nt < 2; ++nt) bias_v[nt] = (a.flags & DSR_F_BIAS) ? a.bias[c0 + wc * 32 + nt * 16 + r16] : 0.f;
 
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tstep = gridDim.x;
@@ -171,14 +172,37 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     asm volatile("" ::: "memory");
     if (do_stats && tid < 128) {
       const int which = tid >> 6, col = tid & 63;
-      a.stats[((size_t)t * 2 + which) * 64 + col] = sStat[0][which][col] + sStat[1][which][col];
+      a.stats[((size_t)t * 2 + which) * a.CoutP + c0 + col] = sStat[0][which][col] + sStat[1][which][col];
     }
-    for (int idx = tid; idx < TR * 32 * 8; idx += 256) {
-      const int prow = idx >> 3, ch = idx & 7;
-      const int oy = oy0 + (prow >> 5), ox = ox0 + (prow & 31);
-      if (oy < a.H && ox < a.W)
-        *reinterpret_cast<U4*>(Y + ((size_t)(n * a.H + oy) * a.W + ox) * 64 + ch * 8) =
-            *reinterpret_cast<const U4*>(sC + prow * C_STRIDE + ch * 16);
+    if (!(a.flags & DSR_F_PIXSHUF)) {
+      for (int idx = tid; idx < TR * 32 * 8; idx += 256) {
+        const int prow = idx >> 3, ch = idx & 7;
+        const int oy = oy0 + (prow >> 5), ox = ox0 + (prow & 31);
+        if (oy < a.H && ox < a.W)
+          *reinterpret_cast<U4*>(Y + ((size_t)(n * a.H + oy) * a.W + ox) * a.CoutP + c0 + ch * 8) =
+              *reinterpret_cast<const U4*>(sC + prow * C_STRIDE + ch * 16);
+      }
+    } else {
+      // PixelShuffle(2): conv channel 4c + 2i + j of pixel (h, w) -> channel c of pixel (2h+i, 2w+j); this slice's 64
+      // conv channels are 16 output channels (two 8-channel vectors) of each of the 4 sub-pixels
+      const int OCp = a.CoutP / 4;
+      for (int idx = tid; idx < TR * 32 * 8; idx += 256) {
+        const int prow = idx >> 3, sub = (idx >> 1) & 3, cq = idx & 1;
+        const int oy = oy0 + (prow >> 5), ox = ox0 + (prow & 31);
+        if (oy < a.H && ox < a.W) {
+          const unsigned short* src = reinterpret_cast<const unsigned short*>(sC + prow * C_STRIDE);
+          unsigned short v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = src[4 * (cq * 8 + q) + sub];
+          U4 o;
+          o.x = v[0] | ((unsigned)v[1] << 16);
+          o.y = v[2] | ((unsigned)v[3] << 16);
+          o.z = v[4] | ((unsigned)v[5] << 16);
+          o.w = v[6] | ((unsigned)v[7] << 16);
+          const int py = 2 * oy + (sub >> 1), px = 2 * ox + (sub & 1);
+          *reinterpret_cast<U4*>(Y + ((size_t)(n * 2 * a.H + py) * (2 * a.W) + px) * OCp + c0 / 4 + cq * 8) = o;
+        }
+      }
     }
   }
 }
@@ -193,7 +217,9 @@ void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st) {
   a.tiles_x = (a.W + 31) / 32;
   a.ntiles = N * a.tiles_y * a.tiles_x;
   a.x_bytes = (unsigned)((size_t)N * a.H * a.W * 128);
-  dim3 grid(a.ntiles < 512 ? a.ntiles : 512), block(256);     // persistent, 2 resident blocks per CU
+  const int slices = a.CoutP / 64;                            // blockIdx.y: 64-channel slice of the output
+  const int per_slice = 512 / slices;                         // 2 resident blocks per CU over all slices
+  dim3 grid(a.ntiles < per_slice ? a.ntiles : per_slice, slices), block(256);
   if (dtype == DSR_DTYPE_BF16)
     hipLaunchKernelGGL((conv_c64_kernel<DSR_DTYPE_BF16>), grid, block, 0, st, a);
   else

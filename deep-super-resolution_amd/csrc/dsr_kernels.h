@@ -113,11 +113,12 @@ int dsr_launch_conv_smalln(SmallNArgs& a, int N, int dtype, hipStream_t st);   /
 struct C64Args {
   const void* x;       // [N][H][W][64]
   const void* w;       // [9][64 rows][64]  (rows = output channels of this GEMM)
-  void* y;             // [N][H][W][64]
+  void* y;             // [N][H][W][CoutP]  (PixelShuffle: [N][2H][2W][CoutP/4])
   const float* bias;
   const float* prelu;
-  float* stats;        // [ntiles][2][64]
+  float* stats;        // [ntiles][2][CoutP]
   int H, W;
+  int CoutP;           // 64 * slices (one 64-channel slice per blockIdx.y; weight image [9][CoutP][64])
   int act;
   float slope;
   int flags;

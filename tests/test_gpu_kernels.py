@@ -79,6 +79,7 @@ CONV_CASES = [
     ("head9x9", 2, 3, 64, 16, 16, 9, 1, 4, 0, "prelu"),
     ("d_first", 2, 3, 64, 16, 24, 3, 1, 1, 0, "leaky"),
     ("d_first_ragged", 3, 3, 64, 37, 70, 3, 1, 1, 0, "leaky"),
+    ("c64_wide_192", 2, 64, 192, 19, 45, 3, 1, 1, 0, "relu"),          # weights-in-registers kernel, 3 output slices
     ("d_s2_64", 2, 64, 64, 16, 16, 3, 2, 1, 0, "none"),
     ("d_s2_odd", 1, 64, 128, 15, 17, 3, 2, 1, 0, "none"),
     ("d_128_256", 1, 128, 256, 8, 8, 3, 1, 1, 0, "relu"),
@@ -178,6 +179,7 @@ BN_CASES = [
     ("g_bn_prelu", 2, 64, 64, 10, 12, 1, 0, "prelu", False, True),
     ("g_bn_res", 2, 64, 64, 10, 12, 1, 0, "none", True, True),
     ("d_bn_leaky_s2", 3, 64, 128, 12, 12, 2, 0, "leaky", False, True),
+    ("d_bn_64_128_s1", 2, 64, 128, 21, 37, 1, 0, "leaky", False, True),   # sliced c64 kernel with statistics rows
     ("dip_bn_reflect", 1, 32, 128, 16, 16, 2, 1, "leaky", False, True),
     ("eval_bn", 2, 64, 64, 8, 8, 1, 0, "prelu", True, False),
 ]
