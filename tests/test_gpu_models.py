@@ -485,3 +485,64 @@ def test_two_rank_gan_step_rehearsal(dev):
     # both exchanges produce the same averaged update (they differ only in fp32 summation order)
     for name, v in sums["1"].items():
         assert abs(v - sums["0"][name]) <= 1e-6 * abs(v), (name, v, sums["0"][name])
+
+
+def test_full_size_batch_split_invariance(dev):
+    """BASELINE config-3 sizes (batch 32, 128x128 -> 512x512), where no CPU oracle finishes in test time: in eval mode
+    every image is independent, so the networks run on the whole batch (the launch shapes bench.py times: persistent
+    and sliced kernels, 16k-tile grids, the 524,288-feature dense head) must reproduce, image for image, what they
+    produce on one image at a time (small grids, one-tile-per-block kernels).  Bit for bit for the generator and
+    the VGG trunk; the discriminator's dense head sums its split-K slabs in a batch-dependent order (1e-5)."""
+    Gm, Dm, GANu = P("models.GAN.generator"), P("models.GAN.discriminator"), P("utils.GAN")
+    torch.manual_seed(3)
+    lr = torch.rand(32, 3, 128, 128, device=dev)
+    with torch.no_grad():
+        gen = Gm.Generator(4, 16).to(dev).eval()
+        sr = gen(lr)
+        assert tuple(sr.shape) == (32, 3, 512, 512) and torch.isfinite(sr).all()
+        for i in (0, 13, 31):
+            assert torch.equal(sr[i:i + 1], gen(lr[i:i + 1].contiguous())), i
+        disc = Dm.Discriminator((512, 512)).to(dev).eval()
+        p = disc(sr)
+        assert tuple(p.shape) == (32, 1) and torch.isfinite(p).all()
+        for i in (0, 31):
+            assert (p[i:i + 1] - disc(sr[i:i + 1].contiguous())).abs().max().item() <= 1e-5, i
+        vgg = GANu.Vgg19Loss().to(dev)
+        f = vgg.features(sr)
+        assert f.shape[0] == 32 and torch.isfinite(f).all()
+        for i in (0, 17):
+            assert torch.equal(f[i:i + 1], vgg.features(sr[i:i + 1].contiguous())), i
+
+
+def test_full_size_gan_step_bookkeeping(dev):
+    """One config-3 step at full size (batch 32, 128x128 -> 512x512, two-stream form): finite losses, every weight tensor of
+    both networks moved and everything stayed finite, BatchNorm counters advanced as train_GAN.py:44-58 implies (generator twice,
+    discriminator three times), and the single-stream form of the same step from the same state gives the same
+    numbers (the streams only reorder independent work)."""
+    Gm, Dm, GANu, steps, optim = (P("models.GAN.generator"), P("models.GAN.discriminator"), P("utils.GAN"), P("steps"),
+                                  P("optim"))
+    torch.manual_seed(5)
+    lr = torch.rand(32, 3, 128, 128, device=dev)
+    hr = torch.rand(32, 3, 512, 512, device=dev) * 2 - 1
+    perc = GANu.PerceptualLoss().to(dev)
+    results = []
+    for overlap in (True, False):
+        torch.manual_seed(11)
+        gen = Gm.Generator(4, 16).to(dev).train()
+        disc = Dm.Discriminator((512, 512)).to(dev).train()
+        # (conv biases in front of a train-mode BatchNorm have an exactly zero gradient and stay put)
+        g0 = {k: p.detach().clone() for k, p in gen.named_parameters() if k.endswith("weight")}
+        d0 = {k: p.detach().clone() for k, p in disc.named_parameters() if k.endswith("weight") and "dense1" not in k}
+        og, od = optim.FusedAdam(gen.parameters(), lr=1e-4), optim.FusedAdam(disc.parameters(), lr=1e-4)
+        ld, lg, fake = steps.gan_step(gen, disc, perc, og, od, lr, hr, overlap=overlap)
+        torch.cuda.synchronize()
+        assert torch.isfinite(ld) and torch.isfinite(lg) and 0.0 < ld.item() < 20.0
+        assert all(torch.isfinite(p).all() for p in gen.parameters()) and all(torch.isfinite(p).all() for p in disc.parameters())
+        assert all(not torch.equal(g0[k], p) for k, p in gen.named_parameters() if k in g0)
+        assert all(not torch.equal(d0[k], p) for k, p in disc.named_parameters() if k in d0)
+        assert all(int(v) == 2 for k, v in gen.state_dict().items() if k.endswith("num_batches_tracked"))
+        assert all(int(v) == 3 for k, v in disc.state_dict().items() if k.endswith("num_batches_tracked"))
+        results.append((ld.item(), lg.item(), float(disc.dense1.weight.detach().double().sum()), float(fake.double().sum())))
+        del gen, disc, og, od
+    a, b = results
+    assert all(abs(x - y) <= 1e-6 * max(1.0, abs(x)) for x, y in zip(a, b)), (a, b)
