@@ -74,6 +74,8 @@ def build_step(workload, dev, world):
         infer = P("infer")
         gen = Gm.Generator(8, 16).to(dev)
         img = torch.rand(1, 3, cfg["lr"], cfg["lr"], generator=torch.Generator().manual_seed(1)).to(dev)
+        if os.environ.get("DSR_HIP_GRAPH", "1") != "0":      # ~150 small launches per image: replay them from a HIP graph
+            return steps.GraphedStep(lambda: infer.super_resolve(gen, img)), (cfg["lr"] * 8) ** 2
         return (lambda: infer.super_resolve(gen, img)), (cfg["lr"] * 8) ** 2
     if workload == "dip_x2":
         M, Dn = P("models.DIP"), P("utils.downsampler")

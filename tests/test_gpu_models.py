@@ -469,8 +469,12 @@ def test_two_rank_gan_step_rehearsal(dev):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DSR_DIST_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    import socket
+    with socket.socket() as sk:                      # any free port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
            "--no-cpu-baseline", "--no-roofline"]
     import json
     import re
