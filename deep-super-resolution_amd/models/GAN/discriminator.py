@@ -77,7 +77,7 @@ class Discriminator(nn.Module):
     def forward(self, x):
         return self.head(self.features(x))
 
-    def forward_pair(self, a, b):
+    def forward_pair(self, a, b, fa=None):
         """(self(a), self(b)) with ONE pass over the dense head.
 
         The conv stack runs separately on each batch, so every train-mode BatchNorm sees exactly the statistics (and
@@ -85,7 +85,9 @@ class Discriminator(nn.Module):
         them on the concatenated batch is arithmetically the same while dense1's K x 1024 weight (2.1 GB at 512x512)
         is streamed once instead of twice in forward, dgrad and wgrad, and its two gradient contributions are summed
         inside the MFMA contraction instead of by a 6 GB elementwise add."""
-        fa, fb = self.features(a), self.features(b)
+        if fa is None:                   # (`fa`: features(a) computed earlier by the caller, e.g. beside the generator forward)
+            fa = self.features(a)
+        fb = self.features(b)
         if fa.shape[0] + fb.shape[0] > 64:
             return self.head(fa), self.head(fb)
         out = self.head(torch.cat([fa, fb], dim=0))

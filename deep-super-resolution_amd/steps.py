@@ -42,7 +42,7 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
     # (with the autograd graph the G step needs) + a double running-stat update is exactly equivalent.
     main = torch.cuda.current_stream(hr_patches.device)
     side = _side_stream(hr_patches.device) if overlap else main
-    hr_feat = None
+    hr_feat = real_feat = None
     if overlap:
         # the VGG features of the HR target depend on nothing but the batch: they run beside the generator forward
         side.wait_stream(main)
@@ -50,6 +50,9 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
             hr_feat = perceptual.vgg_loss.target_features(hr_patches)
             hr_feat_ready = torch.cuda.Event()
             hr_feat_ready.record(side)
+            # ... and so does D's conv trunk on the real batch (:44): same weights, same BatchNorm bookkeeping order
+            # (real before fake) as in the reference, just started while the generator is still running
+            real_feat = disc.features(hr_patches)
     gen.bn_updates = 2
     fake = gen(lr_patches)                                       # :46 and :56
     gen.bn_updates = 1
@@ -58,7 +61,7 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
         side.wait_stream(main)                                   # `fake` is complete before D reads it
 
     def d_half():
-        real_d, fake_d = disc.forward_pair(hr_patches, fake_det)     # :44, :47 (BN statistics per batch, as there)
+        real_d, fake_d = disc.forward_pair(hr_patches, fake_det, fa=real_feat)   # :44, :47 (BN statistics per batch, as there)
         loss_d = F.bce_const(real_d, 1.0) + F.bce_const(fake_d, 0.0)  # :48, utils/GAN.py:101-105
         opt_d.zero_grad()                                        # :51 (gan_D.zero_grad())
         loss_d.backward()                                        # :52
