@@ -40,6 +40,7 @@ SIGNATURES = {
     "dsr_conv_stats_rows": (_I, [_DESC]),
     "dsr_conv_packed_elems": (_Z, [_DESC, _I]),
     "dsr_conv_pack_weight": (_I, [_DESC, _P, _P, _P, _P]),
+    "dsr_conv_pack_weight_multi": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "dsr_conv_fwd": (_I, [_DESC, _P, _P, C.POINTER(Epilogue), _P, _P]),
     "dsr_conv_dgrad_workspace": (_Z, [_DESC]),
     "dsr_conv_dgrad": (_I, [_DESC, _P, _P, _P, _P, _Z, _P]),

@@ -72,6 +72,68 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, unsigned short* 
   }
 }
 
+// All conv weights of an optimiser re-packed in one launch per 48 tensors (after Adam rewrote them): the per-layer
+// launches above are 45 x ~8 us per step for a few MB of data.
+#define DSR_PACK_GROUP 48
+struct PackGroup {
+  const float* w[DSR_PACK_GROUP];
+  unsigned short* wf[DSR_PACK_GROUP];
+  unsigned short* wd[DSR_PACK_GROUP];
+  int cout[DSR_PACK_GROUP], cin[DSR_PACK_GROUP], taps[DSR_PACK_GROUP];
+  unsigned first_block[DSR_PACK_GROUP + 1];
+  int count;
+};
+template <int DT>
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackGroup a) {
+  int t = 0;
+  while (t + 1 < a.count && blockIdx.x >= a.first_block[t + 1]) ++t;      // block-uniform scan
+  const int Cout = a.cout[t], Cin = a.cin[t], T = a.taps[t];
+  const int CoutP = (Cout + 7) & ~7, CinP = (Cin + 7) & ~7;
+  const float* __restrict__ w = a.w[t];
+  const size_t idx = (size_t)(blockIdx.x - a.first_block[t]) * 256 + threadIdx.x;
+  const size_t nf = (size_t)T * CoutP * CinP;                              // both images have T * CoutP * CinP elements
+  if (idx >= nf) return;
+  {
+    const int ci = (int)(idx % CinP);
+    const int co = (int)((idx / CinP) % CoutP);
+    const int tp = (int)(idx / ((size_t)CinP * CoutP));
+    a.wf[t][idx] = f2h<DT>((co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * T + tp] : 0.f);
+  }
+  {
+    const int co = (int)(idx % CoutP);
+    const int ci = (int)((idx / CoutP) % CinP);
+    const int tp = (int)(idx / ((size_t)CoutP * CinP));
+    a.wd[t][idx] = f2h<DT>((co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * T + tp] : 0.f);
+  }
+}
+extern "C" int dsr_conv_pack_weight_multi(int dtype, int count, const float* const* w, void* const* wf, void* const* wd,
+                                          const int* cout, const int* cin, const int* taps, hipStream_t st) {
+  if (count < 0 || (count && (!w || !wf || !wd || !cout || !cin || !taps))) return dsr_fail(DSR_E_ARG, "pack_weight_multi: null table");
+  for (int i0 = 0; i0 < count; i0 += DSR_PACK_GROUP) {
+    PackGroup g;
+    g.count = count - i0 < DSR_PACK_GROUP ? count - i0 : DSR_PACK_GROUP;
+    unsigned blocks = 0;
+    for (int j = 0; j < g.count; ++j) {
+      g.w[j] = w[i0 + j];
+      g.wf[j] = (unsigned short*)wf[i0 + j];
+      g.wd[j] = (unsigned short*)wd[i0 + j];
+      g.cout[j] = cout[i0 + j];
+      g.cin[j] = cin[i0 + j];
+      g.taps[j] = taps[i0 + j];
+      g.first_block[j] = blocks;
+      const size_t n = (size_t)taps[i0 + j] * ((cout[i0 + j] + 7) & ~7) * ((cin[i0 + j] + 7) & ~7);
+      blocks += (unsigned)((n + 255) / 256);
+    }
+    g.first_block[g.count] = blocks;
+    if (!blocks) continue;
+    if (dtype == DSR_BF16)
+      hipLaunchKernelGGL((pack_weight_multi_kernel<DSR_DTYPE_BF16>), dim3(blocks), dim3(256), 0, st, g);
+    else
+      hipLaunchKernelGGL((pack_weight_multi_kernel<DSR_DTYPE_F16>), dim3(blocks), dim3(256), 0, st, g);
+  }
+  return dsr_launch_status("dsr_conv_pack_weight_multi");
+}
+
 // ------------------------------------------------------------------ parallel compaction of partial rows
 // in: [rows][width] fp32 partial sums  ->  out: [nchunks][width], out[c] = sum of rows [c*rpc, (c+1)*rpc).
 // 64 columns x 4 row-lanes per block; fixed summation order => deterministic.  The finalize kernels below then

@@ -108,6 +108,32 @@ def packed_weights(weight, desc, dtype):
     return wf, wd
 
 
+def repack_cached(params):
+    """Refresh, in one launch per 48 tensors, the packed images of every conv weight in `params` that has some (called by
+    the fused optimiser right after it rewrote them; the images are rewritten in place, on the current stream)."""
+    by_dtype = {}
+    for p in params:
+        if p.dim() != 4 or not p.is_contiguous():
+            continue
+        for dtype in (torch.bfloat16, torch.float16):
+            key = (id(p), dtype, tuple(p.shape))
+            hit = _pack_cache.get(key)
+            if hit is not None and hit[3]() is p and hit[0] != _version(p):
+                by_dtype.setdefault(dtype, []).append((key, p, hit))
+    lib = _lib.lib()
+    for dtype, items in by_dtype.items():
+        k = len(items)
+        arr = lambda vals: (C.c_void_p * k)(*vals)
+        ints = lambda vals: (C.c_int * k)(*vals)
+        check(lib.dsr_conv_pack_weight_multi(
+            BF16 if dtype == torch.bfloat16 else F16, k, arr([p.data_ptr() for _, p, _ in items]),
+            arr([h[1].data_ptr() for _, _, h in items]), arr([h[2].data_ptr() for _, _, h in items]),
+            ints([p.shape[0] for _, p, _ in items]), ints([p.shape[1] for _, p, _ in items]),
+            ints([p.shape[2] * p.shape[3] for _, p, _ in items]), _stream()))
+        for key, p, hit in items:
+            _pack_cache[key] = (_version(p), hit[1], hit[2], hit[3])
+
+
 def make_desc(x, cout, kh, kw, stride, pad, pad_mode, cin):
     n, h, w, cp = x.shape
     assert cp == r8(cin), (cp, cin)

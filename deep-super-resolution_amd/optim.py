@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .functional import _ptr, _stream, bump, check, mark_shadow_current, shadow_for_update
+from .functional import _ptr, _stream, bump, check, mark_shadow_current, repack_cached, shadow_for_update
 
 
 class FusedAdam:
@@ -57,3 +57,4 @@ class FusedAdam:
             ns = (C.c_size_t * k)(*[t[0].numel() for t in small])
             check(lib.dsr_pw_adam_multi(k, arr[0], arr[1], arr[2], arr[3], ns, self.lr, self.betas[0], self.betas[1],
                                         self.eps, _ptr(self.step_t), self.grad_scale, st))
+        repack_cached(self.params)           # packed 16-bit conv weight images follow in one launch, not one per layer

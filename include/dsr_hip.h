@@ -69,6 +69,10 @@ size_t dsr_conv_packed_elems(const dsr_conv_desc* d, int dgrad);
 /* w [Cout][Cin][KH][KW] fp32 -> w_fwd [KH*KW][round_up(Cout,8)][round_up(Cin,8)],
  *                               w_dgrad [KH*KW][round_up(Cin,8)][round_up(Cout,8)] (may be NULL) */
 int dsr_conv_pack_weight(const dsr_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad, dsr_stream_t s);
+/* the same packing for `count` weights in one launch per 48 (HOST arrays of device pointers and of Cout / Cin / KH*KW,
+ * read before the call returns): an optimiser refreshes the images of everything it just updated */
+int dsr_conv_pack_weight_multi(int dtype, int count, const float* const* w, void* const* w_fwd, void* const* w_dgrad,
+                               const int* cout, const int* cin, const int* taps, dsr_stream_t s);
 /* y = epilogue(conv(x, w) ) */
 int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w_fwd, const dsr_epilogue* e, void* y,
                  dsr_stream_t s);
