@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
 
 class Epilogue(C.Structure):
     _fields_ = [("act", C.c_int), ("slope", C.c_float), ("prelu", C.c_void_p), ("bias", C.c_void_p),
-                ("stats_partial", C.c_void_p), ("pixel_shuffle", C.c_int), ("out_nchw_f32", C.c_void_p)]
+                ("stats_partial", C.c_void_p), ("pixel_shuffle", C.c_int), ("out_nchw_f32", C.c_void_p),
+                ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("residual", C.c_void_p)]
 
 
 _P, _I, _F, _Z, _LL = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
@@ -33,6 +34,7 @@ SIGNATURES = {
     "dsr_last_error": (C.c_char_p, []),
     "dsr_abi_version": (_I, []),
     "dsr_conv_kernel_name": (C.c_char_p, [_DESC, _I, C.POINTER(Epilogue)]),
+    "dsr_conv_fwd_affine_supported": (_I, [_DESC]),
     "dsr_conv_first_bwd_supported": (_I, [_DESC, _I]),
     "dsr_conv_first_bwd_workspace": (_Z, [_DESC]),
     "dsr_conv_first_bwd": (_I, [_DESC, _P, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),

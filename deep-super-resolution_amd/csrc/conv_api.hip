@@ -83,6 +83,10 @@ static bool is_c64(const dsr_conv_desc* d) {
          d->pad_mode == DSR_PAD_ZERO;
 }
 
+extern "C" int dsr_conv_fwd_affine_supported(const dsr_conv_desc* d) {
+  return d && !check_desc(d) && (is_c64(d) || is_c64_wide(d));
+}
+
 extern "C" int dsr_conv_stats_rows(const dsr_conv_desc* d) {
   int OH, OW;
   if (dsr_conv_out_size(d, &OH, &OW)) return -1;
@@ -166,10 +170,17 @@ extern "C" int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w
     a.OW = OW;
     a.CoutP = r8(d->Cout);
   }
+  const bool fold = e->bn_scale || e->bn_shift || e->residual;
+  if (fold && (!dsr_conv_fwd_affine_supported(d) || e->pixel_shuffle || e->out_nchw_f32 || e->stats_partial ||
+               (!e->bn_scale) != (!e->bn_shift)))
+    return dsr_fail(DSR_E_UNSUPPORTED, "conv_fwd: folded BatchNorm / residual epilogue not available for this layer");
   if (((is_c64(d) && !e->pixel_shuffle) || is_c64_wide(d)) && !e->out_nchw_f32) {
     C64Args c;
     memset(&c, 0, sizeof(c));
     c.CoutP = d->Cout;
+    c.scale = e->bn_scale;
+    c.shift = e->bn_shift;
+    c.res = e->residual;
     c.x = x;
     c.w = w_fwd;
     c.y = y;
@@ -180,7 +191,7 @@ extern "C" int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w
     c.W = d->W;
     c.act = e->act;
     c.slope = e->slope;
-    c.flags = a.flags;
+    c.flags = a.flags | (e->bn_scale ? DSR_F_AFFINE : 0) | (e->residual ? DSR_F_RESIDUAL : 0);
     for (int kh = 0; kh < 3; ++kh)
       for (int kw = 0; kw < 3; ++kw) {
         c.tap_y[kh * 3 + kw] = kh;

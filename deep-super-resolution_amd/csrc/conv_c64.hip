@@ -13,7 +13,8 @@
 #include "dsr_common.h"
 #include "dsr_kernels.h"
 
-template <int DT>
+template <int DT, bool FOLD>     // FOLD: inference epilogue (eval-mode BatchNorm scale/shift, residual); a separate
+                                 // instantiation because the training one has no registers to spare (249 of 256)
 __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   constexpr int HC = 40;                       // halo row pitch in pixels (34 used; multiple of 8 keeps the swizzle row-free)
   constexpr int TR = 2;                        // tile rows (one per wave pair)
@@ -127,6 +128,18 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     const int n = t / per_img;
     const int rem = t - n * per_img;
     const int oy0 = (rem / a.tiles_x) * TR, ox0 = (rem % a.tiles_x) * 32;
+    // inference: eval-mode BatchNorm folded in.  The per-column scale / shift are fetched per tile (L1-resident) rather
+    // than held for the life of the block: the training path has no registers to spare (249 of 256 VGPRs)
+    [[maybe_unused]] float sc_v[2] = {1.f, 1.f}, sh_v[2] = {0.f, 0.f};
+    if constexpr (FOLD) {
+      if (a.flags & DSR_F_AFFINE) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          sc_v[nt] = a.scale[c0 + wc * 32 + nt * 16 + r16];
+          sh_v[nt] = a.shift[c0 + wc * 32 + nt * 16 + r16];
+        }
+      }
+    }
     auto epilogue = [&](auto actf) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int px = i * 16 + 4 * g + r;
-            const float val = acc[i][nt][r] + bias_v[nt];
+            const float val = FOLD ? (acc[i][nt][r] + bias_v[nt]) * sc_v[nt] + sh_v[nt] : acc[i][nt][r] + bias_v[nt];
             const float vm = (oy < a.H && ox0 + px < a.W) ? val : 0.f;
             s1 += vm;
             s2 += vm * vm;
@@ -178,9 +191,19 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
       for (int idx = tid; idx < TR * 32 * 8; idx += 256) {
         const int prow = idx >> 3, ch = idx & 7;
         const int oy = oy0 + (prow >> 5), ox = ox0 + (prow & 31);
-        if (oy < a.H && ox < a.W)
-          *reinterpret_cast<U4*>(Y + ((size_t)(n * a.H + oy) * a.W + ox) * a.CoutP + c0 + ch * 8) =
-              *reinterpret_cast<const U4*>(sC + prow * C_STRIDE + ch * 16);
+        if (oy < a.H && ox < a.W) {
+          const size_t off = ((size_t)(n * a.H + oy) * a.W + ox) * a.CoutP + c0 + ch * 8;
+          U4 v = *reinterpret_cast<const U4*>(sC + prow * C_STRIDE + ch * 16);
+          if (FOLD && (a.flags & DSR_F_RESIDUAL)) {   // skip connection (generator.py:24,74): added after the activation
+            float f[8], rr[8];
+            unpack8<DT>(v, f);
+            unpack8<DT>(*reinterpret_cast<const U4*>(reinterpret_cast<const unsigned short*>(a.res) + off), rr);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) f[q] += rr[q];
+            v = pack8<DT>(f);
+          }
+          *reinterpret_cast<U4*>(Y + off) = v;
+        }
       }
     } else {
       // PixelShuffle(2): conv channel 4c + 2i + j of pixel (h, w) -> channel c of pixel (2h+i, 2w+j); this slice's 64
@@ -220,8 +243,12 @@ void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st) {
   const int slices = a.CoutP / 64;                            // blockIdx.y: 64-channel slice of the output
   const int per_slice = 512 / slices;                         // 2 resident blocks per CU over all slices
   dim3 grid(a.ntiles < per_slice ? a.ntiles : per_slice, slices), block(256);
-  if (dtype == DSR_DTYPE_BF16)
-    hipLaunchKernelGGL((conv_c64_kernel<DSR_DTYPE_BF16>), grid, block, 0, st, a);
-  else
-    hipLaunchKernelGGL((conv_c64_kernel<DSR_DTYPE_F16>), grid, block, 0, st, a);
+  const bool fold = (a.flags & (DSR_F_AFFINE | DSR_F_RESIDUAL)) != 0;
+  if (dtype == DSR_DTYPE_BF16) {
+    if (fold) hipLaunchKernelGGL((conv_c64_kernel<DSR_DTYPE_BF16, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_c64_kernel<DSR_DTYPE_BF16, false>), grid, block, 0, st, a);
+  } else {
+    if (fold) hipLaunchKernelGGL((conv_c64_kernel<DSR_DTYPE_F16, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_c64_kernel<DSR_DTYPE_F16, false>), grid, block, 0, st, a);
+  }
 }

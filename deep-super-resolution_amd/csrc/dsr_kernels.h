@@ -11,6 +11,8 @@
 #define DSR_F_PIXSHUF 4
 #define DSR_F_OUT_NCHW_F32 8
 #define DSR_F_PRELU_PTR 16
+#define DSR_F_AFFINE 32      // (acc + bias) * scale[c] + shift[c] before the activation (eval-mode BatchNorm folded in)
+#define DSR_F_RESIDUAL 64    // + residual tile after the activation
 
 // q = floor(m / d) for 0 <= m < 2^31 via multiply-high (no integer division in kernels)
 struct FastDiv {
@@ -117,6 +119,9 @@ struct C64Args {
   const float* bias;
   const float* prelu;
   float* stats;        // [ntiles][2][CoutP]
+  const float* scale;  // DSR_F_AFFINE: [CoutP]
+  const float* shift;
+  const void* res;     // DSR_F_RESIDUAL: [N][H][W][CoutP]
   int H, W;
   int CoutP;           // 64 * slices (one 64-channel slice per blockIdx.y; weight image [9][CoutP][64])
   int act;

@@ -323,6 +323,13 @@ class ConvBNAct(torch.autograd.Function):
     accumulators; a tiny finalize kernel turns them into the affine map and updates the running
     statistics (momentum 0.1, unbiased variance) exactly like nn.BatchNorm2d."""
 
+    @classmethod
+    def apply(cls, *args):
+        # forward() runs with grad mode off whatever the caller's mode is: note the caller's here ("infer" selects the
+        # single-kernel inference epilogue, which saves nothing for a backward pass)
+        cfg = dict(args[-1], infer=not torch.is_grad_enabled())
+        return super().apply(*args[:-1], cfg)
+
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, nbt, prelu, residual, cfg):
         _need_gpu(x)
@@ -353,11 +360,21 @@ class ConvBNAct(torch.autograd.Function):
                                          int(cfg.get("bn_updates", 1)),
                                          _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
         else:
+            check(lib.dsr_pw_bn_eval_affine(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), BN_EPS,
+                                            cout, cp, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
+            if cfg.get("infer", False) and lib.dsr_conv_fwd_affine_supported(C.byref(desc)):
+                # inference (eval_GAN.py:44,94; called under torch.no_grad(), see apply() below): eval-mode BatchNorm
+                # is a fixed per-channel affine map, so it, the activation and the skip connection all ride in the conv
+                # epilogue -- one kernel, one pass
+                res = residual.contiguous() if residual is not None else None
+                ep = Epilogue(cfg.get("act", ACT_NONE), float(cfg.get("slope", 0.0)), _ptr(prelu), _ptr(bias), None, 0,
+                              None, _ptr(scale), _ptr(shift), _ptr(res))
+                check(_timed("fwd", desc, lambda: lib.dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y),
+                                                                     _stream()), ep))
+                return y
             ep = Epilogue(ACT_NONE, 0.0, None, _ptr(bias), None, 0, None)
             check(_timed("fwd", desc, lambda: lib.dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y),
                                                                  _stream()), ep))
-            check(lib.dsr_pw_bn_eval_affine(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), BN_EPS,
-                                            cout, cp, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
         act = cfg.get("act", ACT_NONE)
         out = torch.empty_like(y)
         res = residual.contiguous() if residual is not None else None

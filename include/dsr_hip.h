@@ -59,7 +59,15 @@ typedef struct dsr_epilogue {
   int pixel_shuffle;       /* 1: store through nn.PixelShuffle(2) (generator.py:32,38):
                               y is [N][2*OH][2*OW][round_up(Cout/4, 8)] */
   float* out_nchw_f32;     /* non-NULL: write fp32 NCHW [N][Cout][OH][OW] here instead of y (last layers) */
+  /* inference-time folding of an eval-mode BatchNorm2d and a skip connection (generator.py:14-25 under gan_G.eval()):
+   * y = act((conv + bias) * bn_scale[c] + bn_shift[c]) + residual.  All NULL for the plain epilogue.  Only layers for
+   * which dsr_conv_fwd_affine_supported() is non-zero accept them; others return DSR_E_UNSUPPORTED. */
+  const float* bn_scale;   /* [round_up(Cout,8)] */
+  const float* bn_shift;   /* [round_up(Cout,8)] */
+  const void* residual;    /* same layout as y */
 } dsr_epilogue;
+
+int dsr_conv_fwd_affine_supported(const dsr_conv_desc* d);
 
 int dsr_conv_out_size(const dsr_conv_desc* d, int* OH, int* OW);
 /* rows of the BatchNorm statistics partial buffer written by dsr_conv_fwd */
