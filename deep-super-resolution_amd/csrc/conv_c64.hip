@@ -31,7 +31,6 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   const int g = lane >> 4, r16 = lane & 15;
   const int wp = wave >> 1, wc = wave & 1;     // tile row, channel half (32 co)
   const int c0 = blockIdx.y * 64;              // this block's slice of the output channels (Cout = 64 * gridDim.y)
-  const unsigned short* __restrict__ X = reinterpret_cast<const unsigned short*>(a.x);
   const unsigned short* __restrict__ W = reinterpret_cast<const unsigned short*>(a.w);
   unsigned short* __restrict__ Y = reinterpret_cast<unsigned short*>(a.y);
 

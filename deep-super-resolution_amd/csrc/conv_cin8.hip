@@ -26,7 +26,6 @@ __global__ __launch_bounds__(256, 3) void conv_cin8_kernel(const Cin8Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, g = lane >> 4;
   unsigned char* sC = smem + SH_BYTES + 256 + wave * SC_WAVE;
-  const unsigned short* X = (const unsigned short*)a.x;
   const unsigned short* Wt = (const unsigned short*)a.w;
   unsigned short* Y = (unsigned short*)a.y;
 

@@ -675,8 +675,6 @@ static void launch_one(const ConvGemmArgs& a, hipStream_t st) {
   }
 }
 
-int dsr_conv_gemm_bm(int /*NB*/) { return 128; }
-
 template <int DT>
 static void dispatch_dt(const ConvGemmArgs& a, hipStream_t st) {
   if (a.NB > 64) {

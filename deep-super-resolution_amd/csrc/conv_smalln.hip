@@ -30,7 +30,6 @@ __global__ __launch_bounds__(512, 2) void conv_smalln_kernel(const SmallNArgs a)
   unsigned char* sW = smem;                              // [tap][WR rows][128 B]
   unsigned char* sX = smem + ntaps * WR * 128;           // [HR][HC][64 ch], 16-byte chunks XOR-swizzled by pixel
   const int per_img = a.tiles_y * a.tiles_x;
-  const unsigned short* __restrict__ X = reinterpret_cast<const unsigned short*>(a.x);
   const unsigned short* __restrict__ W = reinterpret_cast<const unsigned short*>(a.w);
   const int c = tid & 7, pb = tid >> 3;                  // pb in 0..63
 
@@ -330,7 +329,7 @@ int dsr_launch_conv_smalln(SmallNArgs& a, int N, int dtype, hipStream_t st) {
                    : di == 2 ? (const void*)conv_smalln_kernel<DSR_DTYPE_BF16, 3>
                              : (const void*)conv_smalln_kernel<DSR_DTYPE_F16, 3>;
   if (!g_smalln_attr_set[di]) {   // > 64 KB of dynamic LDS needs the opt-in once per kernel (not a stream operation)
-    hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     g_smalln_attr_set[di] = true;
   }
   const size_t P = (size_t)N * a.OH * a.OW;
