@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libdsr_hip.so")
 
 BF16, F16 = 0, 1
-ACT_NONE, ACT_LEAKY, ACT_PRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = range(6)
+ACT_NONE, ACT_LEAKY, ACT_PRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_ELU = range(7)
 PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = range(3)
 
 
@@ -81,6 +81,10 @@ SIGNATURES = {
     "dsr_dense2_bwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "dsr_maxpool2_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "dsr_maxpool2_bwd": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dsr_avgpool2_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
+    "dsr_avgpool2_bwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
+    "dsr_nearest2x_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
+    "dsr_nearest2x_bwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "dsr_bilinear2x_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "dsr_bilinear2x_bwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "dsr_resize_norm_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),

@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define DSR_ACT_RELU 3
 #define DSR_ACT_TANH 4
 #define DSR_ACT_SIGMOID 5
+#define DSR_ACT_ELU 6     // alpha = 1 (nn.ELU() of models/DIP/utils.py:69)
 
 #define DSR_PAD_ZERO 0
 #define DSR_PAD_REFLECT 1
@@ -79,6 +80,7 @@ __device__ __forceinline__ float act_apply(int act, float v, float slope) {
   // branch-light on purpose: this is inlined 64x in the conv epilogue.  tanh/sigmoid share one exp:
   // sigmoid(t) = 1/(1+e^-t), tanh(v) = 2*sigmoid(2v) - 1 (abs error ~1e-7, saturates correctly).
   if (act >= DSR_ACT_TANH) {   // wave-uniform
+    if (act == DSR_ACT_ELU) return v > 0.f ? v : __expf(v) - 1.f;
     const float t = act == DSR_ACT_TANH ? 2.f * v : v;
     const float sg = __fdividef(1.f, 1.f + __expf(-t));
     return act == DSR_ACT_TANH ? 2.f * sg - 1.f : sg;
@@ -92,6 +94,7 @@ __device__ __forceinline__ float act_grad_from_out(int act, float o, float slope
   if (act == DSR_ACT_SIGMOID) return o * (1.f - o);
   if (act == DSR_ACT_NONE) return 1.f;
   if (act == DSR_ACT_RELU) return o > 0.f ? 1.f : 0.f;
+  if (act == DSR_ACT_ELU) return o > 0.f ? 1.f : o + 1.f;   // d/dv (e^v - 1) = o + 1
   return o >= 0.f ? 1.f : slope;
 }
 

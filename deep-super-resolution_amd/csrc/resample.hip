@@ -75,6 +75,84 @@ __global__ void maxpool2_bwd_kernel(const unsigned short* __restrict__ x, const 
   *reinterpret_cast<U4*>(dx + pix * Cp + ch * 8) = pack8<DT>(g);
 }
 
+// ------------------------------------------------------------------ 2x2 average pooling / nearest x2 (DIP options)
+// nn.AvgPool2d(2, 2) (floor mode: an odd trailing row / column is dropped) and its adjoint
+template <int DT>
+__global__ void avgpool2_fwd_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int N, int H,
+                                    int W, int Cp) {
+  const int OH = H / 2, OW = W / 2, cpr = Cp / 8;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)N * OH * OW * cpr;
+  if (idx >= total) return;
+  int ch = (int)(idx % cpr);
+  size_t pix = idx / cpr;
+  int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), n = (int)(pix / ((size_t)OW * OH));
+  const unsigned short* base = x + (((size_t)n * H + 2 * oy) * W + 2 * ox) * Cp + ch * 8;
+  float a[8], b[8], c[8], d[8], o[8];
+  unpack8<DT>(*reinterpret_cast<const U4*>(base), a);
+  unpack8<DT>(*reinterpret_cast<const U4*>(base + Cp), b);
+  unpack8<DT>(*reinterpret_cast<const U4*>(base + (size_t)W * Cp), c);
+  unpack8<DT>(*reinterpret_cast<const U4*>(base + (size_t)W * Cp + Cp), d);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (a[k] + b[k] + c[k] + d[k]) * 0.25f;
+  *reinterpret_cast<U4*>(y + pix * Cp + ch * 8) = pack8<DT>(o);
+}
+template <int DT>
+__global__ void avgpool2_bwd_kernel(const unsigned short* __restrict__ dy, unsigned short* __restrict__ dx, int N,
+                                    int H, int W, int Cp) {
+  const int OH = H / 2, OW = W / 2, cpr = Cp / 8;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)N * H * W * cpr;
+  if (idx >= total) return;
+  int ch = (int)(idx % cpr);
+  size_t pix = idx / cpr;
+  int xx = (int)(pix % W), yy = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
+  float g[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) g[k] = 0.f;
+  if ((yy >> 1) < OH && (xx >> 1) < OW) {
+    unpack8<DT>(*reinterpret_cast<const U4*>(dy + (((size_t)n * OH + (yy >> 1)) * OW + (xx >> 1)) * Cp + ch * 8), g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] *= 0.25f;
+  }
+  *reinterpret_cast<U4*>(dx + pix * Cp + ch * 8) = pack8<DT>(g);
+}
+
+// nn.Upsample(scale_factor=2, mode='nearest'): y[oy][ox] = x[oy/2][ox/2]; the adjoint sums each 2x2 block of dy
+template <int DT>
+__global__ void nearest2x_fwd_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int N, int H,
+                                     int W, int Cp) {
+  const int OH = 2 * H, OW = 2 * W, cpr = Cp / 8;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)N * OH * OW * cpr;
+  if (idx >= total) return;
+  int ch = (int)(idx % cpr);
+  size_t pix = idx / cpr;
+  int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), n = (int)(pix / ((size_t)OW * OH));
+  *reinterpret_cast<U4*>(y + pix * Cp + ch * 8) =
+      *reinterpret_cast<const U4*>(x + (((size_t)n * H + (oy >> 1)) * W + (ox >> 1)) * Cp + ch * 8);
+}
+template <int DT>
+__global__ void nearest2x_bwd_kernel(const unsigned short* __restrict__ dy, unsigned short* __restrict__ dx, int N,
+                                     int H, int W, int Cp) {
+  const int OW = 2 * W, cpr = Cp / 8;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)N * H * W * cpr;
+  if (idx >= total) return;
+  int ch = (int)(idx % cpr);
+  size_t pix = idx / cpr;
+  int xx = (int)(pix % W), yy = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
+  const unsigned short* base = dy + (((size_t)n * 2 * H + 2 * yy) * OW + 2 * xx) * Cp + ch * 8;
+  float a[8], b[8], c[8], d[8], o[8];
+  unpack8<DT>(*reinterpret_cast<const U4*>(base), a);
+  unpack8<DT>(*reinterpret_cast<const U4*>(base + Cp), b);
+  unpack8<DT>(*reinterpret_cast<const U4*>(base + (size_t)OW * Cp), c);
+  unpack8<DT>(*reinterpret_cast<const U4*>(base + (size_t)OW * Cp + Cp), d);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (a[k] + b[k]) + (c[k] + d[k]);
+  *reinterpret_cast<U4*>(dx + pix * Cp + ch * 8) = pack8<DT>(o);
+}
+
 // ------------------------------------------------------------------ bilinear x2 (align_corners = False)
 __device__ __forceinline__ void bil_src(int o, int n_in, int& i0, int& i1, float& l) {
   float s = (o + 0.5f) * 0.5f - 0.5f;
@@ -321,6 +399,34 @@ extern "C" int dsr_maxpool2_bwd(int dtype, const void* x, const void* dy, void* 
                                        (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, N, H, W,
                                        Cp));
   return dsr_launch_status("dsr_maxpool2_bwd");
+}
+extern "C" int dsr_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t st) {
+  size_t total = (size_t)N * (H / 2) * (W / 2) * (Cp / 8);
+  if (total == 0) return 0;
+  DT_SWITCH2(dtype, hipLaunchKernelGGL((avgpool2_fwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
+                                       (const unsigned short*)x, (unsigned short*)y, N, H, W, Cp));
+  return dsr_launch_status("dsr_avgpool2_fwd");
+}
+extern "C" int dsr_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, dsr_stream_t st) {
+  size_t total = (size_t)N * H * W * (Cp / 8);
+  if (total == 0) return 0;
+  DT_SWITCH2(dtype, hipLaunchKernelGGL((avgpool2_bwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
+                                       (const unsigned short*)dy, (unsigned short*)dx, N, H, W, Cp));
+  return dsr_launch_status("dsr_avgpool2_bwd");
+}
+extern "C" int dsr_nearest2x_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t st) {
+  size_t total = (size_t)N * 4 * H * W * (Cp / 8);
+  if (total == 0) return 0;
+  DT_SWITCH2(dtype, hipLaunchKernelGGL((nearest2x_fwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
+                                       (const unsigned short*)x, (unsigned short*)y, N, H, W, Cp));
+  return dsr_launch_status("dsr_nearest2x_fwd");
+}
+extern "C" int dsr_nearest2x_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, dsr_stream_t st) {
+  size_t total = (size_t)N * H * W * (Cp / 8);
+  if (total == 0) return 0;
+  DT_SWITCH2(dtype, hipLaunchKernelGGL((nearest2x_bwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
+                                       (const unsigned short*)dy, (unsigned short*)dx, N, H, W, Cp));
+  return dsr_launch_status("dsr_nearest2x_bwd");
 }
 extern "C" int dsr_bilinear2x_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t st) {
   size_t total = (size_t)N * 4 * H * W * (Cp / 8);

@@ -14,7 +14,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import (ACT_LEAKY, ACT_NONE, ACT_PRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH, BF16, F16,  # noqa: F401
+from ._lib import (ACT_ELU, ACT_LEAKY, ACT_NONE, ACT_PRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH, BF16, F16,  # noqa: F401
                    PAD_REFLECT, PAD_REPLICATE, PAD_ZERO, ConvDesc, Epilogue, check)
 
 BN_EPS = 1e-5
@@ -677,6 +677,48 @@ class MaxPool2(torch.autograd.Function):
         n, h, w, cp = x.shape
         dx = torch.empty_like(x)
         check(_lib.lib().dsr_maxpool2_bwd(_dt(x), _ptr(x), _ptr(dy.contiguous()), _ptr(dx), n, h, w, cp, _stream()))
+        return dx
+
+
+class AvgPool2(torch.autograd.Function):
+    """nn.AvgPool2d(2, 2) on NHWC: conv(..., downsample_mode='avg') of models/DIP/utils.py:86-94."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        n, h, w, cp = x.shape
+        y = torch.empty((n, h // 2, w // 2, cp), dtype=x.dtype, device=x.device)
+        check(_lib.lib().dsr_avgpool2_fwd(_dt(x), _ptr(x), _ptr(y), n, h, w, cp, _stream()))
+        ctx.shape = (n, h, w, cp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, cp = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((n, h, w, cp), dtype=dy.dtype, device=dy.device)
+        check(_lib.lib().dsr_avgpool2_bwd(_dt(dy), _ptr(dy), _ptr(dx), n, h, w, cp, _stream()))
+        return dx
+
+
+class Nearest2x(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2, mode='nearest') on NHWC (models/DIP/skip.py:77, skip()'s default mode)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        n, h, w, cp = x.shape
+        y = torch.empty((n, 2 * h, 2 * w, cp), dtype=x.dtype, device=x.device)
+        check(_lib.lib().dsr_nearest2x_fwd(_dt(x), _ptr(x), _ptr(y), n, h, w, cp, _stream()))
+        ctx.shape = (n, h, w, cp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, cp = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((n, h, w, cp), dtype=dy.dtype, device=dy.device)
+        check(_lib.lib().dsr_nearest2x_bwd(_dt(dy), _ptr(dy), _ptr(dx), n, h, w, cp, _stream()))
         return dx
 
 

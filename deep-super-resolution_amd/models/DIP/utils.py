@@ -7,7 +7,8 @@ Module objects are structure + parameter holders (state_dict keys match the refe
     [ReflectionPad2d] + Conv2d + BatchNorm2d + LeakyReLU  -> one ConvBNAct (padding folded into the tile loader)
     Concat(skip, deeper)                                  -> both branches + channel box-copy with centre crop
     BatchNorm2d on its own                                -> channel-stats + BN-apply kernels
-    Upsample(scale 2, bilinear)                           -> bilinear2x kernel
+    Upsample(scale 2, bilinear | nearest)                 -> bilinear2x / nearest2x kernel
+    Conv2d + AvgPool2d|MaxPool2d (downsample_mode)        -> conv, 2x2 pool kernel, then BN(+act) on the pooled map
     Conv2d + Sigmoid at the very end                      -> conv with sigmoid epilogue, fp32 NCHW output
 The reference's global monkey-patch of ``torch.nn.Module.add`` is not reproduced; ``add`` below is local.
 """
@@ -83,7 +84,8 @@ def conv(in_f, out_f, kernel_size, stride=1, bias=True, pad='zero', downsample_m
 
 # ----------------------------------------------------------------------------- fused executor
 def _conv_parts(seq):
-    """A conv() Sequential -> (Conv2d, pad, pad_mode) or None if `seq` is not one."""
+    """A conv() Sequential -> (Conv2d, pad, pad_mode, pool) or None if `seq` is not one.
+    pool: None | 'avg' | 'max' -- the 2x2 pooling that conv(..., downsample_mode=...) appends (:86-94, :104)."""
     if not isinstance(seq, nn.Sequential) or len(seq) == 0:
         return None
     mods = list(seq.children())
@@ -91,20 +93,45 @@ def _conv_parts(seq):
     if isinstance(mods[0], nn.ReflectionPad2d):
         pad_mode, pad = F.PAD_REFLECT, int(mods[0].padding[0])
         mods = mods[1:]
-    if len(mods) != 1 or not isinstance(mods[0], nn.Conv2d):
-        if mods and isinstance(mods[0], nn.Conv2d):
-            raise NotImplementedError("downsample_mode 'avg'/'max' (pool after conv) is not on the HIP path yet")
+    if not mods or not isinstance(mods[0], nn.Conv2d) or len(mods) > 2:
         return None
+    pool = None
+    if len(mods) == 2:
+        p = mods[1]
+        if isinstance(p, nn.AvgPool2d):
+            pool = 'avg'
+        elif isinstance(p, nn.MaxPool2d):
+            pool = 'max'
+        else:
+            return None
+
+        def _two(v):
+            return all(int(t) == 2 for t in (v if isinstance(v, (tuple, list)) else (v, v)))
+        if not (_two(p.kernel_size) and _two(p.stride)):
+            raise NotImplementedError("only 2x2 / stride-2 pooling after a conv is on the HIP path (skip() never builds another)")
     c = mods[0]
     if pad_mode == F.PAD_ZERO:
         pad = int(c.padding[0])
     elif pad == 0:
         pad_mode = F.PAD_ZERO
-    return c, pad, pad_mode
+    return c, pad, pad_mode, pool
 
 
-def _is_leaky(m):
-    return isinstance(m, nn.LeakyReLU)
+def _act_code(m):
+    """act() module (:62-76) -> (activation code, slope) or None if `m` is not an activation with a kernel."""
+    if isinstance(m, nn.LeakyReLU):
+        return F.ACT_LEAKY, float(m.negative_slope)
+    if isinstance(m, nn.ELU):
+        if float(m.alpha) != 1.0:
+            raise NotImplementedError("nn.ELU with alpha != 1 is not on the HIP path")
+        return F.ACT_ELU, 0.0
+    if isinstance(m, nn.Sequential) and len(m) == 0:       # act('none')
+        return F.ACT_NONE, 0.0
+    if isinstance(m, nn.ReLU):                             # act_fun given as a class (:75-76)
+        return F.ACT_RELU, 0.0
+    if isinstance(m, nn.Tanh):
+        return F.ACT_TANH, 0.0
+    return None
 
 
 def run_fused(seq, x, c, train):
@@ -115,28 +142,25 @@ def run_fused(seq, x, c, train):
         m = mods[i]
         cp = _conv_parts(m)
         if cp is not None:
-            cv, pad, pmode = cp
+            cv, pad, pmode, pool = cp
+            geom = dict(stride=int(cv.stride[0]), pad=pad, pad_mode=pmode)
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             nxt2 = mods[i + 2] if i + 2 < len(mods) else None
-            if isinstance(nxt, nn.BatchNorm2d):
+            if isinstance(nxt, nn.BatchNorm2d) and pool is None:
                 a, slope, step = F.ACT_NONE, 0.0, 2
-                if _is_leaky(nxt2):
-                    a, slope, step = F.ACT_LEAKY, float(nxt2.negative_slope), 3
-                elif isinstance(nxt2, nn.Sequential) and len(nxt2) == 0:       # act('none')
-                    step = 3
-                elif isinstance(nxt2, nn.ELU):
-                    raise NotImplementedError("act_fun='ELU' is not on the HIP path yet")
-                cfg = dict(stride=int(cv.stride[0]), pad=pad, pad_mode=pmode, act=a, slope=slope, train=train)
+                ac = _act_code(nxt2) if nxt2 is not None else None
+                if ac is not None:
+                    (a, slope), step = ac, 3
                 x = F.ConvBNAct.apply(x, cv.weight, cv.bias, nxt.weight, nxt.bias, nxt.running_mean, nxt.running_var,
-                                      nxt.num_batches_tracked, None, None, cfg)
+                                      nxt.num_batches_tracked, None, None, dict(geom, act=a, slope=slope, train=train))
                 c = cv.out_channels
                 i += step
                 continue
-            if isinstance(nxt, nn.Sigmoid) and i + 2 == len(mods):
-                return F.ConvOutNCHW.apply(x, cv.weight, cv.bias, dict(stride=int(cv.stride[0]), pad=pad, pad_mode=pmode,
-                                                                       act=F.ACT_SIGMOID)), cv.out_channels
-            x = F.ConvAct.apply(x, cv.weight, cv.bias, None, dict(stride=int(cv.stride[0]), pad=pad, pad_mode=pmode,
-                                                                   act=F.ACT_NONE))
+            if isinstance(nxt, nn.Sigmoid) and i + 2 == len(mods) and pool is None:
+                return F.ConvOutNCHW.apply(x, cv.weight, cv.bias, dict(geom, act=F.ACT_SIGMOID)), cv.out_channels
+            x = F.ConvAct.apply(x, cv.weight, cv.bias, None, dict(geom, act=F.ACT_NONE))
+            if pool is not None:      # the statistics of a following BatchNorm are those of the POOLED map: no conv fusion
+                x = (F.AvgPool2 if pool == 'avg' else F.MaxPool2).apply(x)
             c = cv.out_channels
             i += 1
             continue
@@ -147,16 +171,17 @@ def run_fused(seq, x, c, train):
             x, c = F.ConcatCrop.apply(ta, tb, ca, cb), ca + cb
         elif isinstance(m, nn.BatchNorm2d):
             a, slope, step = F.ACT_NONE, 0.0, 1
-            if i + 1 < len(mods) and _is_leaky(mods[i + 1]):
-                a, slope, step = F.ACT_LEAKY, float(mods[i + 1].negative_slope), 2
+            ac = _act_code(mods[i + 1]) if i + 1 < len(mods) else None
+            if ac is not None:
+                (a, slope), step = ac, 2
             x = F.BNAct.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked, c,
                               dict(act=a, slope=slope, train=train))
             i += step
             continue
         elif isinstance(m, nn.Upsample):
-            if m.mode != 'bilinear' or float(m.scale_factor) != 2.0:
-                raise NotImplementedError("only Upsample(scale_factor=2, mode='bilinear') is on the HIP path yet")
-            x = F.Bilinear2x.apply(x)
+            if float(m.scale_factor) != 2.0 or m.mode not in ('bilinear', 'nearest') or m.align_corners:
+                raise NotImplementedError("only Upsample(scale_factor=2, mode='bilinear'|'nearest') is on the HIP path")
+            x = (F.Bilinear2x if m.mode == 'bilinear' else F.Nearest2x).apply(x)
         elif isinstance(m, nn.Sequential):
             x, c = run_fused(m, x, c, train)
         elif isinstance(m, nn.Sigmoid):

@@ -50,7 +50,7 @@ typedef struct dsr_conv_desc {
 
 /* fused epilogue of the forward conv */
 typedef struct dsr_epilogue {
-  int act;                 /* 0 none, 1 leaky(slope), 2 prelu(*prelu), 3 relu, 4 tanh, 5 sigmoid */
+  int act;                 /* 0 none, 1 leaky(slope), 2 prelu(*prelu), 3 relu, 4 tanh, 5 sigmoid, 6 elu(alpha=1) */
   float slope;
   const float* prelu;      /* 1-element device tensor (nn.PReLU(), generator.py:9,34,48) or NULL */
   const float* bias;       /* [Cout] or NULL */
@@ -194,6 +194,13 @@ int dsr_dense2_bwd(int dtype, const float* dout, const float* out, const float* 
 /* nn.MaxPool2d(2,2) of the VGG19 trunk (utils/GAN.py:24,29,38,47); backward routes to the first maximum */
 int dsr_maxpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t s);
 int dsr_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int Cp, dsr_stream_t s);
+/* nn.AvgPool2d(2,2) after a stride-1 conv: downsample_mode='avg' of models/DIP/utils.py:86-94 (floor mode);
+ * H, W are the INPUT size of the pool.  downsample_mode='max' uses dsr_maxpool2_* above. */
+int dsr_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t s);
+int dsr_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, dsr_stream_t s);
+/* nn.Upsample(scale_factor=2, mode='nearest') (models/DIP/skip.py:77, the builder's default); H, W = INPUT size */
+int dsr_nearest2x_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t s);
+int dsr_nearest2x_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, dsr_stream_t s);
 /* nn.Upsample(scale_factor=2, mode='bilinear') (models/DIP/skip.py:77); H, W are the INPUT size */
 int dsr_bilinear2x_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t s);
 int dsr_bilinear2x_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, dsr_stream_t s);

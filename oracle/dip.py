@@ -6,8 +6,9 @@ Follows /root/reference:
   models/DIP/skip.py:3-96       skip(): nested encoder-decoder, module names 1-indexed
   models/DIP/utils.py:5-8       nn.Module.add -> names "1","2",...
   models/DIP/utils.py:18-38     Concat with centre crop to the smallest H, W
-  models/DIP/utils.py:62-76     act(): LeakyReLU(0.2)
+  models/DIP/utils.py:62-76     act(): LeakyReLU(0.2) | ELU | none
   models/DIP/utils.py:83-105    conv(): [ReflectionPad2d(int((k-1)/2))] + Conv2d(k, stride, padding 0)
+                                [+ AvgPool2d|MaxPool2d(stride, stride) after a stride-1 conv when downsample_mode != 'stride']
   utils/DIP.py:70-96            fill_noise / get_noise
 """
 import torch
@@ -20,7 +21,8 @@ class SkipConfig:
     """Arguments of get_net (models/DIP/__init__.py:8) reduced to what skip() consumes."""
 
     def __init__(self, input_depth=32, n_channels=3, skip_n33d=128, skip_n33u=128, skip_n11=4,
-                 num_scales=5, pad="reflection", upsample_mode="bilinear"):
+                 num_scales=5, pad="reflection", upsample_mode="bilinear", act_fun="LeakyReLU",
+                 downsample_mode="stride"):
         self.input_depth = input_depth
         self.n_channels = n_channels
         self.down = [skip_n33d] * num_scales if isinstance(skip_n33d, int) else list(skip_n33d)
@@ -30,6 +32,9 @@ class SkipConfig:
         assert all(c != 0 for c in self.skip), "oracle restates the Concat branch only"
         self.pad = pad
         self.upsample_mode = upsample_mode
+        assert act_fun in ("LeakyReLU", "ELU", "none") and downsample_mode in ("stride", "avg", "max")
+        self.act_fun = act_fun
+        self.downsample_mode = downsample_mode
         self.ci = 1 if pad == "reflection" else 0   # index of the Conv2d inside conv()'s Sequential
 
 
@@ -69,18 +74,28 @@ def skip_shapes(cfg):
     return s
 
 
-def _conv(sd, key, x, k, stride, cfg):
-    """models/DIP/utils.py:83-105 with downsample_mode == 'stride'."""
+def _conv(sd, key, x, k, stride, cfg, downsample_mode="stride"):
+    """models/DIP/utils.py:83-105."""
+    pool = None
+    if stride != 1 and downsample_mode != "stride":                   # :86-94
+        pool = F.avg_pool2d if downsample_mode == "avg" else F.max_pool2d
+        pool_k, stride = stride, 1
     to_pad = int((k - 1) / 2)
     if cfg.pad == "reflection":
         if to_pad:
             x = F.pad(x, (to_pad,) * 4, mode="reflect")
         to_pad = 0
-    return F.conv2d(x, sd[key + ".weight"], sd[key + ".bias"], stride=stride, padding=to_pad)
+    y = F.conv2d(x, sd[key + ".weight"], sd[key + ".bias"], stride=stride, padding=to_pad)
+    return pool(y, pool_k, pool_k) if pool is not None else y
 
 
-def _act(x):
-    return F.leaky_relu(x, 0.2)
+def _act_of(cfg):
+    """models/DIP/utils.py:62-76."""
+    if cfg.act_fun == "LeakyReLU":
+        return lambda x: F.leaky_relu(x, 0.2)
+    if cfg.act_fun == "ELU":
+        return F.elu
+    return lambda x: x
 
 
 def concat_center_crop(inputs):
@@ -98,12 +113,13 @@ def concat_center_crop(inputs):
 def skip_forward(sd, x, cfg, train=True):
     n = len(cfg.down)
     c = str(cfg.ci)
+    _act = _act_of(cfg)
 
     def level(P, i, x):
         last = i == n - 1
         s = _conv(sd, P + "1.0.1." + c, x, 1, 1, cfg)
         s = _act(batch_norm(sd, P + "1.0.2", s, train))
-        d = _conv(sd, P + "1.1.1." + c, x, 3, 2, cfg)
+        d = _conv(sd, P + "1.1.1." + c, x, 3, 2, cfg, cfg.downsample_mode)
         d = _act(batch_norm(sd, P + "1.1.2", d, train))
         d = _conv(sd, P + "1.1.4." + c, d, 3, 1, cfg)
         d = _act(batch_norm(sd, P + "1.1.5", d, train))

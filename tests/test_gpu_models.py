@@ -167,6 +167,30 @@ def test_maxpool_bilinear_concat(dev):
     yg.backward(to_nhwc(probe).to(dev))
     assert rel_err(from_nhwc(yg.detach().cpu(), 8), yr.detach()) < 5e-3
     assert rel_err(from_nhwc(xg.grad.cpu(), 8), xr.grad) < 5e-3
+    # nearest x2 (a copy forward, a 4-term fp32 sum rounded once backward)
+    x = bfr(filler.tensor("nn:x", (2, 11, 5, 7)))
+    xr = x.clone().requires_grad_(True)
+    yr = TF.interpolate(xr, scale_factor=2, mode="nearest")
+    probe = bfr(filler.tensor("nn:p", tuple(yr.shape)))
+    (yr * probe).sum().backward()
+    xg = to_nhwc(x).to(dev).requires_grad_(True)
+    yg = F.Nearest2x.apply(xg)
+    yg.backward(to_nhwc(probe).to(dev))
+    assert torch.equal(from_nhwc(yg.detach().cpu(), 11), yr.detach())
+    assert rel_err(from_nhwc(xg.grad.cpu(), 11), xr.grad) < 4e-3       # one bf16 rounding of an fp32 sum
+    # average pool 2x2, odd sizes (floor mode drops the trailing row / column; their gradient is zero)
+    x = bfr(filler.tensor("ap:x", (2, 9, 7, 10)))
+    xr = x.clone().requires_grad_(True)
+    yr = TF.avg_pool2d(xr, 2, 2)
+    probe = bfr(filler.tensor("ap:p", tuple(yr.shape)))
+    (yr * probe).sum().backward()
+    xg = to_nhwc(x).to(dev).requires_grad_(True)
+    yg = F.AvgPool2.apply(xg)
+    assert tuple(yg.shape) == (2, 3, 5, 16)
+    yg.backward(to_nhwc(probe).to(dev))
+    assert rel_err(from_nhwc(yg.detach().cpu(), 9), yr.detach()) < 4e-3
+    assert torch.equal(from_nhwc(xg.grad.cpu(), 9), bfr(xr.grad))      # dy / 4 is exact in bf16
+    assert float(xg.grad[:, 6].float().abs().max()) == 0.0
     # concat with centre crop, channel counts that are not multiples of 8
     a = bfr(filler.tensor("cc:a", (1, 4, 10, 12)))
     b = bfr(filler.tensor("cc:b", (1, 13, 8, 8)))
@@ -328,6 +352,16 @@ def test_vgg_loss(dev):
 
 DIP_CASES = [("small", (1, 8, 32, 32), dict(skip_n33d=16, skip_n33u=16, skip_n11=4, num_scales=3)),
              ("full64", (1, 32, 64, 64), {}), ("crop72x104", (1, 32, 72, 104), {})]
+_S3 = dict(skip_n33d=16, skip_n33u=16, skip_n11=4, num_scales=3)
+# get_net's optional arguments (models/DIP/__init__.py:8): act_fun, downsample_mode, upsample_mode
+DIP_CASES += [
+    ("opt_elu_avg_nearest", (1, 8, 32, 32), dict(_S3, act_fun="ELU", downsample_mode="avg", upsample_mode="nearest")),
+    ("opt_none_max_bilinear", (1, 8, 32, 32), dict(_S3, act_fun="none", downsample_mode="max", upsample_mode="bilinear")),
+    ("opt_leaky_avg_nearest_odd", (1, 8, 36, 44), dict(_S3, act_fun="LeakyReLU", downsample_mode="avg",
+                                                       upsample_mode="nearest")),
+    ("opt_elu_stride_nearest_b2", (2, 8, 32, 48), dict(_S3, act_fun="ELU", downsample_mode="stride",
+                                                       upsample_mode="nearest")),
+]
 
 
 @pytest.mark.parametrize("tag,shape,kw", DIP_CASES)
@@ -335,20 +369,24 @@ def test_dip_skip_net(dev, tag, shape, kw):
     M = P("models.DIP")
     cfg = dip.SkipConfig(input_depth=shape[1], **kw)
     sd = filler.fill_state_dict(gan.template(dip.skip_shapes(cfg)))
-    net = M.get_net(shape[1], "skip", "reflection", upsample_mode="bilinear", **kw)
+    nkw = dict(kw)
+    net = M.get_net(shape[1], "skip", "reflection", upsample_mode=nkw.pop("upsample_mode", "bilinear"), **nkw)
     assert set(net.state_dict().keys()) == set(sd.keys())
     net.load_state_dict(sd)
     net.to(dev).train()
     x = filler.tensor("in:dipg_" + tag, shape, 0.05, 0.05)
     xg = x.to(dev).requires_grad_(True)
     y = net(xg)
-    assert y.dtype == torch.float32 and tuple(y.shape) == (shape[0], 3, shape[2], shape[3])
+    assert y.dtype == torch.float32
+    if "odd" not in tag:      # sizes that do not halve evenly are centre-cropped by Concat: shape checked against the oracle
+        assert tuple(y.shape) == (shape[0], 3, shape[2], shape[3])
     probe = filler.tensor("probe:dipg_" + tag, tuple(y.shape))
     (y * probe.to(dev)).sum().backward()
     osd = {k: v.clone() for k, v in sd.items()}
     recipes.leaves(osd)
     xr = x.clone().requires_grad_(True)
     yr = dip.skip_forward(osd, xr, cfg, True)
+    assert tuple(yr.shape) == tuple(y.shape)
     (yr * probe).sum().backward()
     # fp16-storage floor of the same computation (oracle/lowp.py); SkipNet computes in fp16 by default
     assert net.compute_dtype == torch.float16

@@ -150,6 +150,16 @@ def test_discriminator(golden, hw):
 DIP_CASES = [("sq64", (1, 32, 64, 64), {}), ("r64x96", (1, 32, 64, 96), {}), ("crop72x104", (1, 32, 72, 104), {}),
              ("b2_64", (2, 32, 64, 64), {}),
              ("small", (1, 8, 32, 32), dict(skip_n33d=16, skip_n33u=16, skip_n11=4, num_scales=3))]
+_S3 = dict(skip_n33d=16, skip_n33u=16, skip_n11=4, num_scales=3)
+# get_net's optional arguments (act_fun / downsample_mode / upsample_mode), same cases as make_golden.DIP_OPTION_CASES
+DIP_CASES += [
+    ("opt_elu_avg_nearest", (1, 8, 32, 32), dict(_S3, act_fun="ELU", downsample_mode="avg", upsample_mode="nearest")),
+    ("opt_none_max_bilinear", (1, 8, 32, 32), dict(_S3, act_fun="none", downsample_mode="max", upsample_mode="bilinear")),
+    ("opt_leaky_avg_nearest_odd", (1, 8, 36, 44), dict(_S3, act_fun="LeakyReLU", downsample_mode="avg",
+                                                       upsample_mode="nearest")),
+    ("opt_elu_stride_nearest_b2", (2, 8, 32, 48), dict(_S3, act_fun="ELU", downsample_mode="stride",
+                                                       upsample_mode="nearest")),
+]
 
 
 @pytest.mark.parametrize("tag,shape,kw", DIP_CASES)
