@@ -48,9 +48,9 @@ class FusedAdam:
             else:
                 check(lib.dsr_pw_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), self.lr, self.betas[0],
                                       self.betas[1], self.eps, _ptr(self.step_t), self.grad_scale, _ptr(sh), st))
-                if sh is not None:
-                    mark_shadow_current(p)
             bump(p)
+            if sh is not None:               # after bump(): the shadow written by this launch IS the new version
+                mark_shadow_current(p)
         if small:                            # every small tensor in one launch per 64 (dsr_pw_adam_multi)
             k = len(small)
             arr = [(C.c_void_p * k)(*[t[i].data_ptr() for t in small]) for i in range(4)]

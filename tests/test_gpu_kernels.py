@@ -349,6 +349,27 @@ def test_adam_multi_tensor_matches_per_tensor(dev):
         assert rel_err(a[i].detach().cpu(), r[i].detach()) < 1e-6, i
 
 
+def test_adam_keeps_the_dense_shadow_current(dev):
+    """The bf16 image of the dense head's matrix (functional.shadow16) is rewritten by the Adam launch itself and must
+    be recognised as current afterwards: no second cast pass per step, and never a stale image."""
+    F, optim = P("functional"), P("optim")
+    w = filler.tensor("sh:w", (24, 136)).to(dev).requires_grad_(True)
+    sh0 = F.shadow16(w, torch.bfloat16)
+    assert torch.equal(sh0, w.detach().to(torch.bfloat16))
+    opt = optim.FusedAdam([w], lr=1e-2)
+    for it in range(2):
+        w.grad = filler.tensor(f"sh:g{it}", (24, 136)).to(dev)
+        opt.step()
+        key = (id(w), torch.bfloat16, tuple(w.shape))
+        assert F._shadow_cache[key][0] == F._version(w)                 # marked current: shadow16 will not re-cast
+        sh = F.shadow16(w, torch.bfloat16)
+        assert sh.data_ptr() == sh0.data_ptr()
+        assert torch.equal(sh, w.detach().to(torch.bfloat16))
+    with torch.no_grad():                                               # an outside in-place edit must invalidate it
+        w.mul_(0.5)
+    assert torch.equal(F.shadow16(w, torch.bfloat16), w.detach().to(torch.bfloat16))
+
+
 PERSIST_CASES = [  # name, N, H, W, Cin, Cout, stride, act, stats, pixel_shuffle
     ("fwd_128_stats", 4, 192, 192, 64, 128, 1, 0, True, False),
     ("fwd_128_leaky", 4, 192, 192, 64, 128, 1, 1, False, False),
