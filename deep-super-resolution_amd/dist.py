@@ -11,15 +11,24 @@ gradient is not exchanged at all: the discriminator's dense1.weight gradient is 
 between two GPUs would need ~30 ms for its all-reduce), but it is the product of two small rank-local factors
 (dy^T: 128 KB, x^T: 67 MB).  functional.DenseHead all-gathers those and forms the rank-averaged gradient itself
 (``dsr_linear_wgrad_gathered``); this module marks the tensor and skips it.  Other tensors of at least ``big_bytes``
-are reduced in place, each as its own message, from autograd's post-accumulate hook; everything smaller is packed into
-flat buckets of ``bucket_bytes``.  Collectives are issued asynchronously and only waited for right before the optimiser.
+are reduced in place, each as its own message, from autograd's post-accumulate hook; everything smaller is packed (one
+fused multi-tensor copy) into persistent flat buckets of ``bucket_bytes`` whose slices then serve as the .grad tensors, so
+nothing is copied back.  RCCL averages inside the collective (ReduceOp.AVG).  Collectives are issued asynchronously and
+only waited for right before the optimiser.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
+# DSR_DIST_FORCE=1 (development aid): treat an initialised world-size-1 process group as data parallel, so that every
+# collective of the N > 1 path (broadcast, hook-issued and bucketed all-reduce, factor all-gather) is really issued --
+# on a one-GPU box that is the only way to run them through RCCL ("nccl") rather than gloo.
+FORCE = os.environ.get("DSR_DIST_FORCE", "0") == "1"
+
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE)
 
 
 def broadcast_module(module, src=0):
@@ -47,6 +56,7 @@ class GradSync:
         self._pending = []
         self._early = set()
         self._hooks = []
+        self._plan_key, self._buckets = None, []
 
     def attach(self, factor_gather=True):
         """``factor_gather``: 2-D parameters of at least ``big_bytes`` (the dense head's K x 1024 matrix) are marked
@@ -55,7 +65,6 @@ class GradSync:
         all-reduced from its post-accumulate hook."""
         if not is_dist() or self._hooks:
             return self
-        import os
         factor_gather = factor_gather and os.environ.get("DSR_DP_FACTOR_GATHER", "1") != "0"   # 0: plain all-reduce
         for p in self.params:
             if p.numel() * p.element_size() >= self.big_bytes:
@@ -65,51 +74,79 @@ class GradSync:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
         return self
 
+    @staticmethod
+    def _reduce_op():
+        """(op, divide): RCCL averages inside the collective; gloo has no AVG, so sum and divide afterwards."""
+        if dist.get_backend() == "nccl":
+            return dist.ReduceOp.AVG, False
+        return dist.ReduceOp.SUM, True
+
     def _on_grad_ready(self, p):
         if not is_dist() or p.grad is None:
             return
-        work = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True)
-        self._pending.append(("big", work, p.grad, None, dist.get_world_size()))
+        op, divide = self._reduce_op()
+        work = dist.all_reduce(p.grad, op=op, async_op=True)
+        self._pending.append(("big", work, p.grad, None, divide))
         self._early.add(id(p))
+
+    def _plan(self, small):
+        """Persistent flat buckets for the small gradients: [(flat, [(param, view of flat shaped like param), ...]), ...].
+        Slots start on 256-byte boundaries (the fused Adam reads .grad with 16-byte vector loads)."""
+        key = tuple((id(p), p.grad.dtype) for p in small)
+        if key == self._plan_key:
+            return self._buckets
+        groups, cur, size = [], [], 0
+        for p in small:
+            if cur and (p.grad.dtype != cur[0].grad.dtype or size >= self.bucket_bytes):
+                groups.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += p.grad.numel() * p.grad.element_size()
+        if cur:
+            groups.append(cur)
+        self._buckets = []
+        for grp in groups:
+            align = 256 // grp[0].grad.element_size()
+            offs, total = [], 0
+            for p in grp:
+                offs.append(total)
+                total += (p.numel() + align - 1) // align * align
+            flat = torch.zeros(total, dtype=grp[0].grad.dtype, device=grp[0].grad.device)
+            self._buckets.append((flat, [(p, flat[o:o + p.numel()].view_as(p)) for p, o in zip(grp, offs)]))
+        self._plan_key = key
+        return self._buckets
 
     def launch(self):
         """Start averaging every .grad that has not been started by a hook (call right after backward)."""
         if not is_dist():
             return
-        world = dist.get_world_size()
-        small, size = [], 0
+        op, divide = self._reduce_op()
+        small = []
         for p in reversed(self.params):          # reverse registration order ~ order grads became ready
             g = p.grad
             if g is None or id(p) in self._early or getattr(p, "_dsr_grad_global", False):
                 continue
-            nbytes = g.numel() * g.element_size()
-            if nbytes >= self.big_bytes:
-                self._pending.append(("big", dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True), g, None, world))
-                continue
-            small.append(g)
-            size += nbytes
-            if size >= self.bucket_bytes:
-                self._flush(small, world)
-                small, size = [], 0
-        if small:
-            self._flush(small, world)
-
-    def _flush(self, grads, world):
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-        self._pending.append(("bucket", work, flat, list(grads), world))
+            if g.numel() * g.element_size() >= self.big_bytes or not g.is_contiguous():
+                self._pending.append(("big", dist.all_reduce(g, op=op, async_op=True), g, None, divide))
+            else:
+                small.append(p)
+        for flat, items in self._plan(small):
+            # one fused multi-tensor copy packs the bucket; after the collective the views BECOME the .grad tensors
+            # (wait()), so nothing is copied back -- per-tensor copies cost ~140 launches per optimiser and step
+            torch._foreach_copy_([v for _, v in items], [p.grad for p, _ in items])
+            self._pending.append(("bucket", dist.all_reduce(flat, op=op, async_op=True), flat, items, divide))
 
     def wait(self):
-        """Block the current stream until the averages have landed in the .grad tensors."""
-        for kind, work, buf, grads, world in self._pending:
+        """Block the current stream until the averages have landed; afterwards every small parameter's .grad is a view
+        of its bucket (valid until the next launch(), like DDP's gradient_as_bucket_view)."""
+        world = dist.get_world_size() if self._pending else 1
+        for kind, work, buf, items, divide in self._pending:
             work.wait()
-            buf.div_(world)
+            if divide:
+                buf.div_(world)
             if kind == "bucket":
-                off = 0
-                for g in grads:
-                    n = g.numel()
-                    g.copy_(buf[off:off + n].view_as(g))
-                    off += n
+                for p, v in items:
+                    p.grad = v
         self._pending = []
         self._early = set()
 

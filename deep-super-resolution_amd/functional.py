@@ -557,11 +557,11 @@ def mark_shadow_current(weight):
 
 def dp_world_for(param):
     """World size when `param`'s gradient is produced already averaged over the ranks by its own backward
-    (`param._dsr_grad_global`, set by dist.GradSync.attach for the dense head's big matrix), else 1."""
+    (`param._dsr_grad_global`, set by dist.GradSync.attach for the dense head's big matrix), else 0."""
     if not getattr(param, "_dsr_grad_global", False):
-        return 1
+        return 0
     import torch.distributed as dist
-    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 0
 
 
 def _gather_factors(xt, dyt, world):
@@ -636,7 +636,7 @@ class DenseHead(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             xt = torch.empty((k, bp), dtype=x.dtype, device=dev)
             check(lib.dsr_flatten(_dt(x), _ptr(x), _ptr(xt), n, hw, c, cp, bp, 1, st))
-            if ctx.dp_world > 1:
+            if ctx.dp_world >= 1:     # (1 only under DSR_DIST_FORCE=1: the RCCL path rehearsed on a single rank)
                 # data parallel: the averaged dW1 = (1/R) sum_r dyT_r xT_r is formed from the all-gathered rank-local factors
                 # (67 MB + 128 KB per rank) instead of all-reducing the 2.1 GB gradient; dist.GradSync skips this tensor
                 gather = _gather_factors(xt, dyt16, ctx.dp_world)

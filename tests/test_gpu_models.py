@@ -529,6 +529,35 @@ def test_two_rank_gan_step_rehearsal(dev):
         assert abs(v - sums["0"][name]) <= 1e-6 * abs(v), (name, v, sums["0"][name])
 
 
+def test_rccl_single_rank_gan_step(dev):
+    """The same N > 1 code path through RCCL itself (backend "nccl"), which a one-GPU box can only run as a world of ONE
+    rank (DSR_DIST_FORCE=1): broadcast, bucketed all-reduce (ReduceOp.AVG) into the persistent bucket views, the factor
+    all-gather / the hook-issued 2 GB all-reduce, all on the two streams of the overlapped step.  With one rank the
+    averaged update IS the local update, so the parameters must match a run without any process group."""
+    import json
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
+    sums = {}
+    for tag, extra in (("plain", dict(DSR_BENCH_CHECKSUM="1")), ("gather", dict(DSR_DIST_FORCE="1")),
+                       ("allreduce", dict(DSR_DIST_FORCE="1", DSR_DP_FACTOR_GATHER="0"))):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", **extra)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert out["n_gpus"] == 1 and out["value"] > 0
+        sums[tag] = {m.group(1): float(m.group(2)) for m in re.finditer(r"checksum (\w+) ([0-9.e+-]+)", r.stderr)}
+        assert set(sums[tag]) == {"Generator", "Discriminator"}, r.stderr[-2000:]
+    for tag in ("gather", "allreduce"):
+        for name, v in sums["plain"].items():
+            assert abs(v - sums[tag][name]) <= 1e-6 * abs(v), (tag, name, v, sums[tag][name])
+
+
 def test_full_size_batch_split_invariance(dev):
     """BASELINE config-3 sizes (batch 32, 128x128 -> 512x512), where no CPU oracle finishes in test time: in eval mode
     every image is independent, so the networks run on the whole batch (the launch shapes bench.py times: persistent
