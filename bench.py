@@ -245,8 +245,9 @@ def main():
     step, px_per_rank = build_step(a.workload, dev, world)
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        if world > 1 or force:
+            # (device_ids: the group is not bound to a device at init, so name the one this rank's barrier runs on)
+            dist.barrier(device_ids=[local]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     def note(msg):

@@ -713,34 +713,48 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
                                                    float b1, float b2, float eps, const int* __restrict__ step,
                                                    float grad_scale, unsigned short* __restrict__ shadow16) {
+  // A pure stream (28 B per parameter, nothing re-read): two 16-byte vectors per thread and tensor in flight and
+  // nontemporal accesses measured 6.3 TB/s against 5.8 for the one-vector cached form (537 M parameters).
+  typedef __attribute__((ext_vector_type(4))) float F4;
+  typedef __attribute__((ext_vector_type(2))) unsigned U2;
   const int t = *step;
   const float bc1 = 1.f - powf(b1, (float)t);
   const float rbc2 = 1.f / sqrtf(1.f - powf(b2, (float)t));
   const float step_size = lr / bc1;
   const size_t n4 = n / 4;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 pi = reinterpret_cast<float4*>(p)[i], gi = reinterpret_cast<const float4*>(g)[i];
-    float4 mi = reinterpret_cast<float4*>(m)[i], vi = reinterpret_cast<float4*>(v)[i];
-    float* pp = &pi.x;
-    float* gp = &gi.x;
-    float* mp = &mi.x;
-    float* vp = &vi.x;
+  const size_t stride = (size_t)gridDim.x * 512;
+  for (size_t i0 = (size_t)blockIdx.x * 512 + threadIdx.x; i0 < n4; i0 += stride) {
+    F4 pi[2], gi[2], mi[2], vi[2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float gk = gp[k] * grad_scale;   // 1/S un-does a static loss scale (fp16 storage); 1 otherwise
-      mp[k] = b1 * mp[k] + (1.f - b1) * gk;
-      vp[k] = b2 * vp[k] + (1.f - b2) * gk * gk;
-      pp[k] -= step_size * (mp[k] / (sqrtf(vp[k]) * rbc2 + eps));
+    for (int u = 0; u < 2; ++u) {
+      const size_t i = i0 + u * 256;
+      if (i < n4) {
+        pi[u] = __builtin_nontemporal_load(reinterpret_cast<const F4*>(p) + i);
+        gi[u] = __builtin_nontemporal_load(reinterpret_cast<const F4*>(g) + i);
+        mi[u] = __builtin_nontemporal_load(reinterpret_cast<const F4*>(m) + i);
+        vi[u] = __builtin_nontemporal_load(reinterpret_cast<const F4*>(v) + i);
+      }
     }
-    reinterpret_cast<float4*>(p)[i] = pi;
-    reinterpret_cast<float4*>(m)[i] = mi;
-    reinterpret_cast<float4*>(v)[i] = vi;
-    if (shadow16) {   // bf16 image of the updated parameter (dense1's MFMA operand) without a separate cast pass
-      uint2 h;
-      h.x = (unsigned)f2h<DSR_DTYPE_BF16>(pi.x) | ((unsigned)f2h<DSR_DTYPE_BF16>(pi.y) << 16);
-      h.y = (unsigned)f2h<DSR_DTYPE_BF16>(pi.z) | ((unsigned)f2h<DSR_DTYPE_BF16>(pi.w) << 16);
-      reinterpret_cast<uint2*>(shadow16)[i] = h;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t i = i0 + u * 256;
+      if (i >= n4) continue;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gk = gi[u][k] * grad_scale;   // 1/S un-does a static loss scale (fp16 storage); 1 otherwise
+        mi[u][k] = b1 * mi[u][k] + (1.f - b1) * gk;
+        vi[u][k] = b2 * vi[u][k] + (1.f - b2) * gk * gk;
+        pi[u][k] -= step_size * (mi[u][k] / (sqrtf(vi[u][k]) * rbc2 + eps));
+      }
+      __builtin_nontemporal_store(pi[u], reinterpret_cast<F4*>(p) + i);
+      __builtin_nontemporal_store(mi[u], reinterpret_cast<F4*>(m) + i);
+      __builtin_nontemporal_store(vi[u], reinterpret_cast<F4*>(v) + i);
+      if (shadow16) {   // bf16 image of the updated parameter (dense1's MFMA operand) without a separate cast pass
+        U2 h;
+        h.x = (unsigned)f2h<DSR_DTYPE_BF16>(pi[u].x) | ((unsigned)f2h<DSR_DTYPE_BF16>(pi[u].y) << 16);
+        h.y = (unsigned)f2h<DSR_DTYPE_BF16>(pi[u].z) | ((unsigned)f2h<DSR_DTYPE_BF16>(pi[u].w) << 16);
+        __builtin_nontemporal_store(h, reinterpret_cast<U2*>(shadow16) + i);
+      }
     }
   }
   // tail (n not a multiple of 4): the first threads of block 0
@@ -898,8 +912,8 @@ extern "C" int dsr_pw_bce_const(const float* p, int n, float target, float* loss
 }
 extern "C" int dsr_pw_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                  const int* step, float grad_scale, void* shadow_bf16, hipStream_t st) {
-  size_t want = (n / 4 + 255) / 256;
-  unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+  size_t want = (n / 4 + 511) / 512;
+  unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 65536 ? 65536 : want));
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, step, grad_scale,
                      (unsigned short*)shadow_bf16);
   return dsr_launch_status("dsr_pw_adam");
