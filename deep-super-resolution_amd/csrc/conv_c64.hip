@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   const int hr0 = pb / HC, hc0 = pb - hr0 * HC;
   const int per_img = a.tiles_y * a.tiles_x;
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   auto fetch = [&](int t, int buf) {
     const int n = t / per_img;
@@ -90,9 +92,17 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   const int tstep = gridDim.x;
   if (t < a.ntiles) fetch(t, 0);
   int buf = 0;
+  bool first = true;
   for (; t < a.ntiles; t += tstep, buf ^= 1) {
-    // my DMA of this tile is done; after the barrier everyone's is, and every wave is past the previous tile
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // my DMA of this tile is done; after the barrier everyone's is, and every wave is past the previous tile.
+    // The previous tile's two output stores per thread (always issued: range-checked buffer stores) are younger than
+    // this tile's DMA and stay in flight through the MFMA phase: vmcnt retires in order, so "at most 2 outstanding"
+    // already means the DMA has landed.  A vmcnt(0) here exposed the full store latency once per 72-MFMA tile.
+    if (first)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    first = false;
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (t + tstep < a.ntiles) fetch(t + tstep, buf ^ 1);
@@ -187,43 +197,46 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
       a.stats[((size_t)t * 2 + which) * a.CoutP + c0 + col] = sStat[0][which][col] + sStat[1][which][col];
     }
     if (!(a.flags & DSR_F_PIXSHUF)) {
-      for (int idx = tid; idx < TR * 32 * 8; idx += 256) {
+#pragma unroll
+      for (int it = 0; it < TR * 32 * 8 / 256; ++it) {          // exactly 2 stores per thread (see the wait above)
+        const int idx = tid + it * 256;
         const int prow = idx >> 3, ch = idx & 7;
         const int oy = oy0 + (prow >> 5), ox = ox0 + (prow & 31);
-        if (oy < a.H && ox < a.W) {
-          const size_t off = ((size_t)(n * a.H + oy) * a.W + ox) * a.CoutP + c0 + ch * 8;
-          U4 v = *reinterpret_cast<const U4*>(sC + prow * C_STRIDE + ch * 16);
-          if (FOLD && (a.flags & DSR_F_RESIDUAL)) {   // skip connection (generator.py:24,74): added after the activation
-            float f[8], rr[8];
-            unpack8<DT>(v, f);
-            unpack8<DT>(*reinterpret_cast<const U4*>(reinterpret_cast<const unsigned short*>(a.res) + off), rr);
+        const bool ok = oy < a.H && ox < a.W;
+        const size_t off = ok ? ((size_t)(n * a.H + oy) * a.W + ox) * a.CoutP + c0 + ch * 8 : 0;
+        U4 v = *reinterpret_cast<const U4*>(sC + prow * C_STRIDE + ch * 16);
+        if (FOLD && (a.flags & DSR_F_RESIDUAL)) {   // skip connection (generator.py:24,74): added after the activation
+          float f[8], rr[8];
+          unpack8<DT>(v, f);
+          unpack8<DT>(*reinterpret_cast<const U4*>(reinterpret_cast<const unsigned short*>(a.res) + off), rr);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) f[q] += rr[q];
-            v = pack8<DT>(f);
-          }
-          *reinterpret_cast<U4*>(Y + off) = v;
+          for (int q = 0; q < 8; ++q) f[q] += rr[q];
+          v = pack8<DT>(f);
         }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrsrc, ok ? (unsigned)(off * 2) : OOB, 0, 0);
       }
     } else {
       // PixelShuffle(2): conv channel 4c + 2i + j of pixel (h, w) -> channel c of pixel (2h+i, 2w+j); this slice's 64
       // conv channels are 16 output channels (two 8-channel vectors) of each of the 4 sub-pixels
       const int OCp = a.CoutP / 4;
-      for (int idx = tid; idx < TR * 32 * 8; idx += 256) {
+#pragma unroll
+      for (int it = 0; it < TR * 32 * 8 / 256; ++it) {          // exactly 2 stores per thread
+        const int idx = tid + it * 256;
         const int prow = idx >> 3, sub = (idx >> 1) & 3, cq = idx & 1;
         const int oy = oy0 + (prow >> 5), ox = ox0 + (prow & 31);
-        if (oy < a.H && ox < a.W) {
-          const unsigned short* src = reinterpret_cast<const unsigned short*>(sC + prow * C_STRIDE);
-          unsigned short v[8];
+        const bool ok = oy < a.H && ox < a.W;
+        const unsigned short* src = reinterpret_cast<const unsigned short*>(sC + prow * C_STRIDE);
+        unsigned short v[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = src[4 * (cq * 8 + q) + sub];
-          U4 o;
-          o.x = v[0] | ((unsigned)v[1] << 16);
-          o.y = v[2] | ((unsigned)v[3] << 16);
-          o.z = v[4] | ((unsigned)v[5] << 16);
-          o.w = v[6] | ((unsigned)v[7] << 16);
-          const int py = 2 * oy + (sub >> 1), px = 2 * ox + (sub & 1);
-          *reinterpret_cast<U4*>(Y + ((size_t)(n * 2 * a.H + py) * (2 * a.W) + px) * OCp + c0 / 4 + cq * 8) = o;
-        }
+        for (int q = 0; q < 8; ++q) v[q] = src[4 * (cq * 8 + q) + sub];
+        U4 o;
+        o.x = v[0] | ((unsigned)v[1] << 16);
+        o.y = v[2] | ((unsigned)v[3] << 16);
+        o.z = v[4] | ((unsigned)v[5] << 16);
+        o.w = v[6] | ((unsigned)v[7] << 16);
+        const int py = 2 * oy + (sub >> 1), px = 2 * ox + (sub & 1);
+        const size_t off = ((size_t)(n * 2 * a.H + py) * (2 * a.W) + px) * OCp + c0 / 4 + cq * 8;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, ok ? (unsigned)(off * 2) : OOB, 0, 0);
       }
     }
   }
@@ -239,6 +252,7 @@ void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st) {
   a.tiles_x = (a.W + 31) / 32;
   a.ntiles = N * a.tiles_y * a.tiles_x;
   a.x_bytes = (unsigned)((size_t)N * a.H * a.W * 128);
+  a.y_bytes = (unsigned)((size_t)N * a.H * a.W * a.CoutP * 2);   // (PixelShuffle: [N][2H][2W][CoutP/4] is the same size)
   const int slices = a.CoutP / 64;                            // blockIdx.y: 64-channel slice of the output
   const int per_slice = 512 / slices;                         // 2 resident blocks per CU over all slices
   dim3 grid(a.ntiles < per_slice ? a.ntiles : per_slice, slices), block(256);
