@@ -10,10 +10,32 @@
 // so the MFMA phase touches LDS only.  Same epilogue contract as conv_gemm (bias, activation, BatchNorm
 // sum / sum-of-squares rows -- one row per spatial TILE here --, 16-byte NHWC stores).  dgrad = the same kernel on the
 // [tap][ci][co] weight image with mirrored tap offsets.
+#include <cstdlib>
+#include <type_traits>
+
 #include "dsr_common.h"
 #include "dsr_kernels.h"
 
-template <int DT, bool FOLD>     // FOLD: inference epilogue (eval-mode BatchNorm scale/shift, residual); a separate
+#ifdef DSR_C64_STAMPS
+__device__ unsigned long long g_c64_stamps[16];
+extern "C" int dsr_debug_c64(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c64_stamps), sizeof(g_c64_stamps));
+}
+#define STAMP(k) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define STAMP(k)
+#endif
+// one v_max_f32 (fmaxf adds a canonicalising v_max(x, x) per operand)
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// MODE 0: pixel-major accumulators, can emit BatchNorm statistics; 1: swapped accumulators (no statistics);
+// 2: swapped + FOLD, the inference epilogue (eval-mode BatchNorm scale/shift, residual).  Separate instantiations: the
+// layouts need different per-lane constants and the kernel has no registers to spare.
+template <int DT, int MODE>      // FOLD: inference epilogue (eval-mode BatchNorm scale/shift, residual); a separate
                                  // instantiation because the training one has no registers to spare (249 of 256)
 __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   constexpr int HC = 40;                       // halo row pitch in pixels (34 used; multiple of 8 keeps the swizzle row-free)
@@ -34,7 +56,18 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   const unsigned short* __restrict__ W = reinterpret_cast<const unsigned short*>(a.w);
   unsigned short* __restrict__ Y = reinterpret_cast<unsigned short*>(a.y);
 
-  // ---- weights: registers, once (B operand: rows = output channels wc*32 + nt*16 + r16)
+  // Two accumulator layouts (uniform per launch).  Launches that emit BatchNorm statistics keep pixels on the MFMA's M
+  // axis: a lane then holds 4 PIXELS of one channel and the per-channel sums need two cross-row shuffles.  All other
+  // launches swap the operands (weights on M): a lane holds 4 consecutive CHANNELS of one pixel, which leave as one
+  // 8-byte LDS write after two packed conversions instead of four 2-byte writes.  For PixelShuffle(2) launches the
+  // weight rows of each 16-channel tile are taken in the order m -> 4 (m & 3) + (m >> 2), so that those 4 values are
+  // the 4 consecutive output channels of ONE sub-pixel (conv channel 4c + s -> sub-pixel s, channel c).
+  constexpr bool FOLD = MODE == 2;
+  constexpr bool swp = MODE != 0;
+  const bool do_stats = MODE == 0 && (a.flags & DSR_F_STATS) != 0;
+  const bool pixshuf = (a.flags & DSR_F_PIXSHUF) != 0;
+  const int wrow = (swp && pixshuf) ? 4 * (r16 & 3) + (r16 >> 2) : r16;
+  // ---- weights: registers, once (rows = output channels wc*32 + nt*16 + wrow)
   U4 fw[9][2][2];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -42,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
-        fw[t][kk][nt] = *reinterpret_cast<const U4*>(W + ((size_t)(t * a.CoutP + c0 + wc * 32 + nt * 16 + r16)) * 64 + kk * 32 + g * 8);
+        fw[t][kk][nt] = *reinterpret_cast<const U4*>(W + ((size_t)(t * a.CoutP + c0 + wc * 32 + nt * 16 + wrow)) * 64 + kk * 32 + g * 8);
 
   // A-fragment LDS offsets: pixel column (tx + r16) -> (tx + r16)*128 + swizzled chunk; + row*HC*128 + hx*2048
   int lds_off[3][2];
@@ -53,47 +86,137 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
 
   // loader: LDS-DMA (buffer_load ... lds): wave-instruction u of wave w fills halo slots 32u + 8w .. +7 (8 pixels x
   // 128 B, lane-linear), slot position (lane & 7) of pixel q holding channel chunk (lane & 7) ^ (q & 7); an
-  // out-of-range offset writes zeros (image border, pad columns 34..39).  The tile never passes through VGPRs.
-  const int c = (tid & 7) ^ ((tid >> 3) & 7), pb = tid >> 3;
+  // out-of-range offset writes zeros.  The tile never passes through VGPRs.
+  // Everything outside the MFMA phase competes with the partner block's MFMAs for the SIMD's issue port (s_memtime
+  // stamps: MFMA phase 30 % of a tile, fetch 17 %, epilogue + stores 50 %), so per-tile vector work is kept minimal:
+  // every address is a tile-invariant per-lane part (computed once per launch) plus a per-tile SCALAR part, the image
+  // ROWS outside [0, H) are rejected by the buffer range check of a per-image resource, and the COLUMN check runs only
+  // for tiles that touch the left / right image edge.
   constexpr int NV = (HRW * HC + 31) / 32;     // 5
-  const int hr0 = pb / HC, hc0 = pb - hr0 * HC;
-  const int per_img = a.tiles_y * a.tiles_x;
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
+  constexpr int FAR = 0x7FFFFF00;              // lane part of a slot that is never fetched: any scalar part leaves it out of range
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  auto fetch = [&](int t, int buf) {
-    const int n = t / per_img;
-    const int rem = t - n * per_img;
-    const int oy0 = (rem / a.tiles_x) * TR - 1, ox0 = (rem % a.tiles_x) * 32 - 1;
-    int hr = hr0, hc = hc0;
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+  const int per_img = a.tiles_y * a.tiles_x;
+  const unsigned img_bytes = (unsigned)(a.H * a.W * 128);
+  int ld_part[NV];                             // ((hr * W + hc) * 64 + chunk * 8) * 2 of this lane's slot
+  unsigned hc_pack = 0;                        // its halo column, 6 bits per wave-instruction
+  {
+    const int c = (tid & 7) ^ ((tid >> 3) & 7), pb = tid >> 3;
+    int hr = pb / HC, hc = pb - hr * HC;
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-      const int iy = oy0 + hr, ix = ox0 + hc;
-      const bool ok = hr < HRW && hc < 34 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(smem + buf * X_BYTES + (32 * u + 8 * wave) * 128), 16,
-                                               ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * 64 + c * 8) * 2) : OOB, 0, 0, 0);
+      ld_part[u] = (hr < HRW && hc < 34) ? ((hr * a.W + hc) * 64 + c * 8) * 2 : FAR;   // pad columns 34..39 are never read
+      hc_pack |= (unsigned)hc << (6 * u);
       hc += 32;
       if (hc >= HC) {
         hc -= HC;
         ++hr;
       }
     }
+  }
+  // Tile coordinates (image, tile row, tile column) are carried along and advanced by the decomposed grid stride:
+  // four integer divisions per tile were ~240 dependent scalar instructions, a sixth of a tile's time.
+  struct TileXY {
+    int n, ty, tx;
+  };
+  auto decomp = [&](int t) {
+    TileXY c;
+    c.n = t / per_img;
+    const int rem = t - c.n * per_img;
+    c.ty = rem / a.tiles_x;
+    c.tx = rem - c.ty * a.tiles_x;
+    return c;
+  };
+  const TileXY tstep_xy = decomp((int)gridDim.x);
+  auto advance = [&](TileXY c) {
+    c.tx += tstep_xy.tx;
+    if (c.tx >= a.tiles_x) {
+      c.tx -= a.tiles_x;
+      ++c.ty;
+    }
+    c.ty += tstep_xy.ty;
+    if (c.ty >= a.tiles_y) {
+      c.ty -= a.tiles_y;
+      ++c.n;
+    }
+    c.n += tstep_xy.n;
+    return c;
+  };
+  auto fetch = [&](const TileXY& tc, int buf) {
+    const int n = tc.n;
+    const int oy0 = tc.ty * TR - 1, ox0 = tc.tx * 32 - 1;                         // all scalar
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x)) + (size_t)n * img_bytes, 0, img_bytes, 0x00020000);
+    const int sbase = (oy0 * a.W + ox0) * 128;                                    // may be negative (row -1): out of range
+    unsigned char* dst = smem + buf * X_BYTES + 8 * wave * 128;
+    if (ox0 >= 0 && ox0 + 34 <= a.W) {                                            // interior columns: no per-lane check
+#pragma unroll
+      for (int u = 0; u < NV; ++u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + 32 * u * 128), 16, (unsigned)(ld_part[u] + sbase), 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int ix = ox0 + (int)((hc_pack >> (6 * u)) & 63);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + 32 * u * 128), 16,
+                                                 (unsigned)ix < (unsigned)a.W ? (unsigned)(ld_part[u] + sbase) : OOB, 0, 0, 0);
+      }
+    }
   };
 
   const float slope = (a.flags & DSR_F_PRELU_PTR) ? a.prelu[0] : a.slope;
-  const bool do_stats = (a.flags & DSR_F_STATS) != 0;
-  float bias_v[2];
+  // channel of accumulator register r of n-tile nt: pixel-major layout: wc*32 + nt*16 + r16 (all r);
+  // swapped: wc*32 + nt*16 + (4g + r), through the PixelShuffle row order: wc*32 + nt*16 + 4r + g
+  auto chan = [&](int nt, int r) {
+    return wc * 32 + nt * 16 + (!swp ? r16 : (pixshuf ? 4 * r + g : 4 * g + r));
+  };
+  constexpr int NB = swp ? 4 : 1;              // distinct channels among a lane's 4 accumulator registers
+  float bias_v[2][NB];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) bias_v[nt] = (a.flags & DSR_F_BIAS) ? a.bias[c0 + wc * 32 + nt * 16 + r16] : 0.f;
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < NB; ++r) bias_v[nt][r] = (a.flags & DSR_F_BIAS) ? a.bias[c0 + chan(nt, r)] : 0.f;
+
+  // C tile in LDS: pixel rows of 64 channels.  PixelShuffle(2) launches store channel 4c + s at byte s*32 + c*2, i.e.
+  // already grouped by sub-pixel, so that the store loop reads whole 16-byte vectors in both layouts.
+  int cw_base[2];                              // this lane's write address in the C tile for n-tile nt:
+#pragma unroll                                 //   pixel-major: pixel (wp*32 + 4g [+ 16 i + r]), one channel;
+  for (int nt = 0; nt < 2; ++nt) {             //   swapped: pixel (wp*32 + r16 [+ 16 i]), 4 channels (8 bytes)
+    const int col = wc * 32 + nt * 16 + r16;
+    if constexpr (!swp)
+      cw_base[nt] = (wp * 32 + 4 * g) * C_STRIDE + (pixshuf ? (col & 3) * 32 + (col >> 2) * 2 : col * 2);
+    else
+      cw_base[nt] = (wp * 32 + r16) * C_STRIDE + (pixshuf ? g * 32 + (wc * 8 + nt * 4) * 2 : (wc * 32 + nt * 16 + 4 * g) * 2);
+  }
+  // store loop: thread tid moves the 16-byte vectors idx = tid, tid + 256 of the tile (pixel idx >> 3, vector idx & 7)
+  const int cr_base = (tid >> 3) * C_STRIDE + (tid & 7) * 16;          // + it * 32 * C_STRIDE
+  const int st_row = tid >> 8;                                         // 0 (kept for clarity: idx >> 8 selects `it`)
+  (void)st_row;
+  int st_part;                                                          // byte offset of vector `tid` relative to the tile origin
+  int st_step;                                                          // ... and of vector tid + 256 relative to vector tid
+  if (!pixshuf) {
+    st_part = ((tid >> 3) & 31) * a.CoutP * 2 + (tid & 7) * 16;       // prow = tid >> 3 (0..31): row 0 of the tile
+    st_step = a.W * a.CoutP * 2;                                       // prow + 32: row 1
+  } else {
+    const int OCp = a.CoutP / 4;
+    const int sub = (tid >> 1) & 3, cq = tid & 1, pxc = (tid >> 3) & 31;
+    st_part = ((sub >> 1) * 2 * a.W + 2 * pxc + (sub & 1)) * OCp * 2 + cq * 16;
+    st_step = 2 * (2 * a.W) * OCp * 2;                                 // conv row + 1 = output rows + 2
+  }
 
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tstep = gridDim.x;
-  if (t < a.ntiles) fetch(t, 0);
+  TileXY cur = decomp(t), nxt = advance(cur);
+  if (t < a.ntiles) fetch(cur, 0);
   int buf = 0;
   bool first = true;
+#ifdef DSR_C64_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
   for (; t < a.ntiles; t += tstep, buf ^= 1) {
+    STAMP(0);
     // my DMA of this tile is done; after the barrier everyone's is, and every wave is past the previous tile.
     // The previous tile's two output stores per thread (always issued: range-checked buffer stores) are younger than
     // this tile's DMA and stay in flight through the MFMA phase: vmcnt retires in order, so "at most 2 outstanding"
@@ -105,141 +228,212 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     first = false;
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + tstep < a.ntiles) fetch(t + tstep, buf ^ 1);
+    STAMP(1);
+    if (t + tstep < a.ntiles) fetch(nxt, buf ^ 1);
     const unsigned char* sX = smem + buf * X_BYTES;
+    STAMP(2);
 
     f32x4 acc[2][2];                           // m-tile = half hx of the wave's row ; n-tile nt
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int k = 0; k < 2; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < 2; ++k)                // bias: free here
+        acc[i][k] = f32x4{bias_v[k][0], bias_v[k][1 % NB], bias_v[k][2 % NB], bias_v[k][3 % NB]};
+    // tap order is a compile-time property of each branch (forward: tap t = (t/3, t%3); dgrad: mirrored), so every
+    // A-fragment address is a per-lane base register + an immediate: no address arithmetic between the MFMAs.
+    // The 18 (tap, k-half) units run as a software pipeline: the two A fragments of unit u + 2 are requested before
+    // the 4 MFMAs of unit u (three register sets), so an LDS read has 8 MFMAs (128 cycles) to land instead of being
+    // waited for right after its issue -- hipcc otherwise reuses one register set and exposes the LDS latency 18 times.
+    auto mfma_phase = [&](auto mirror, auto swapped) {
+      constexpr bool MIR = decltype(mirror)::value;
+      constexpr bool SWP = decltype(swapped)::value;
+      const unsigned char* rowp0 = sX + wp * HC * 128;
+      U4 fa[3][2];
+      auto load = [&](int u, U4* dst) {
+        const int tp = u >> 1, kk = u & 1;
+        const int ty = MIR ? 2 - tp / 3 : tp / 3, tx = MIR ? 2 - tp % 3 : tp % 3;
+        const unsigned char* rowp = rowp0 + ty * HC * 128;
+        dst[0] = *reinterpret_cast<const U4*>(rowp + lds_off[tx][kk]);
+        dst[1] = *reinterpret_cast<const U4*>(rowp + 2048 + lds_off[tx][kk]);
+      };
+      load(0, fa[0]);
+      load(1, fa[1]);
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-      const int ty = a.tap_y[tp], tx = a.tap_x[tp];   // uniform, 0..2 (halo-relative)
-      const unsigned char* rowp = sX + (wp + ty) * HC * 128;
-      const int o0 = tx == 0 ? lds_off[0][0] : (tx == 1 ? lds_off[1][0] : lds_off[2][0]);
-      const int o1 = tx == 0 ? lds_off[0][1] : (tx == 1 ? lds_off[1][1] : lds_off[2][1]);
-      U4 fa[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[0][i] = *reinterpret_cast<const U4*>(rowp + i * 2048 + o0);
-        fa[1][i] = *reinterpret_cast<const U4*>(rowp + i * 2048 + o1);
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+      for (int u = 0; u < 18; ++u) {
+        if (u + 2 < 18) load(u + 2, fa[(u + 2) % 3]);
+        __builtin_amdgcn_sched_barrier(0);       // (the machine scheduler would sink the reads back to their use)
+        const int tp = u >> 1, kk = u & 1;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc[i][nt] = mfma16<DT>(fa[kk][i], fw[tp][kk][nt], acc[i][nt]);
-    }
-
-    // ---- epilogue
-    const int n = t / per_img;
-    const int rem = t - n * per_img;
-    const int oy0 = (rem / a.tiles_x) * TR, ox0 = (rem % a.tiles_x) * 32;
-    // inference: eval-mode BatchNorm folded in.  The per-column scale / shift are fetched per tile (L1-resident) rather
-    // than held for the life of the block: the training path has no registers to spare (249 of 256 VGPRs)
-    [[maybe_unused]] float sc_v[2] = {1.f, 1.f}, sh_v[2] = {0.f, 0.f};
-    if constexpr (FOLD) {
-      if (a.flags & DSR_F_AFFINE) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          sc_v[nt] = a.scale[c0 + wc * 32 + nt * 16 + r16];
-          sh_v[nt] = a.shift[c0 + wc * 32 + nt * 16 + r16];
-        }
+          for (int nt = 0; nt < 2; ++nt)
+            acc[i][nt] = SWP ? mfma16<DT>(fw[tp][kk][nt], fa[u % 3][i], acc[i][nt]) : mfma16<DT>(fa[u % 3][i], fw[tp][kk][nt], acc[i][nt]);
+        __builtin_amdgcn_sched_barrier(0);
       }
+    };
+    // The co-resident wave of the other block on this SIMD is, most of the time, in its own MFMA phase.  Vector issue is
+    // arbitrated by priority, then age: at equal priority this wave's ~75 epilogue / store / fetch instructions got about
+    // one issue slot per two partner MFMAs (s_memtime stamps: 2,400 cycles for them against 1,150 cycles of MFMA work).
+    // Everything outside the MFMA phase therefore runs at priority 1; the MFMA stream fills the slots that leaves.
+    __builtin_amdgcn_s_setprio(0);
+    if (a.tap_y[0] == 0)
+      mfma_phase(std::false_type{}, std::integral_constant<bool, swp>{});
+    else
+      mfma_phase(std::true_type{}, std::integral_constant<bool, swp>{});
+    __builtin_amdgcn_s_setprio(1);
+
+    STAMP(3);
+#ifdef DSR_C64_STAMPS
+    asm volatile("v_mov_b32 %0, %0" : "+v"(acc[1][1][3]));      // first read of an accumulator: the MFMA queue has drained
+#endif
+    // ---- epilogue
+    const int n = cur.n;
+    const int oy0 = cur.ty * TR, ox0 = cur.tx * 32;
+    cur = nxt;
+    nxt = advance(nxt);
+    const bool full = oy0 + TR <= a.H && ox0 + 32 <= a.W;      // uniform: ragged tiles only at the bottom / right edge
+    // inference: eval-mode BatchNorm folded in.  The per-column scale / shift are fetched per tile (L1-resident) rather
+    // than held for the life of the block: the training path has no registers to spare
+    [[maybe_unused]] float sc_v[2][NB], sh_v[2][NB];
+    if constexpr (FOLD) {
+      const bool aff = (a.flags & DSR_F_AFFINE) != 0;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+          sc_v[nt][r] = aff ? a.scale[c0 + chan(nt, r)] : 1.f;
+          sh_v[nt][r] = aff ? a.shift[c0 + chan(nt, r)] : 0.f;
+        }
     }
-    auto epilogue = [&](auto actf) {
+    // SM: 0 no statistics, 1 statistics of a full tile, 2 statistics of a ragged tile (out-of-image pixels masked)
+    static_assert(16 * C_STRIDE == 2304, "immediate of the second ds_write_b64 below");
+    const unsigned sC_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)sC);
+    const unsigned cw_lds[2] = {sC_lds + (unsigned)cw_base[0], sC_lds + (unsigned)cw_base[1]};
+    auto epilogue = [&](auto actf, auto smode) {
+      constexpr int SM = decltype(smode)::value;
+      if constexpr (SM == 3) {                 // swapped layout (never with statistics): 4 channels of one pixel per lane
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = actf(FOLD ? acc[i][nt][r] * sc_v[nt][r] + sh_v[nt][r] : acc[i][nt][r]);
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            u32x2 pk;
+            if constexpr (DT == DSR_DTYPE_BF16) {
+              typedef __attribute__((ext_vector_type(2))) __bf16 h2;
+              pk.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, h2));
+              pk.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, h2));
+            } else {
+              typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+              pk.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, h2));
+              pk.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, h2));
+            }
+            // inline asm: behind an in-flight LDS-DMA hipcc puts s_waitcnt vmcnt(0) in front of an 8-byte LDS store
+            // it can see (the next tile's halo and the previous tile's output stores would be drained here)
+#ifdef DSR_C64_NOWRITE
+            asm volatile("" ::"v"(cw_lds[nt]), "v"(pk) : "memory");
+            continue;
+#endif
+            if (i == 0)
+              asm volatile("ds_write_b64 %0, %1" ::"v"(cw_lds[nt]), "v"(pk) : "memory");
+            else
+              asm volatile("ds_write_b64 %0, %1 offset:2304" ::"v"(cw_lds[nt]), "v"(pk) : "memory");   // 16 * C_STRIDE
+          }
+        return;
+      }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        const int col = wc * 32 + nt * 16 + r16;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int oy = oy0 + wp;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int px = i * 16 + 4 * g + r;
-            const float val = FOLD ? (acc[i][nt][r] + bias_v[nt]) * sc_v[nt] + sh_v[nt] : acc[i][nt][r] + bias_v[nt];
-            const float vm = (oy < a.H && ox0 + px < a.W) ? val : 0.f;
-            s1 += vm;
-            s2 += vm * vm;
-            const int prow = wp * 32 + px;                       // pixel index inside the tile
-            *reinterpret_cast<unsigned short*>(sC + prow * C_STRIDE + col * 2) = f2h<DT>(actf(val));
+            const float val = acc[i][nt][r];             // (FOLD launches are always swapped)
+            if constexpr (SM != 0) {
+              float vm = val;
+              if constexpr (SM == 2) vm = (oy0 + wp < a.H && ox0 + i * 16 + 4 * g + r < a.W) ? val : 0.f;
+              s1 += vm;
+              s2 += vm * vm;
+            }
+            *reinterpret_cast<unsigned short*>(sC + cw_base[nt] + (i * 16 + r) * C_STRIDE) = f2h<DT>(actf(val));
           }
         }
-        if (do_stats) {
+        if constexpr (SM != 0) {
           s1 += __shfl_xor(s1, 16, 64);
           s1 += __shfl_xor(s1, 32, 64);
           s2 += __shfl_xor(s2, 16, 64);
           s2 += __shfl_xor(s2, 32, 64);
           if (g == 0) {
-            sStat[wp][0][col] = s1;
-            sStat[wp][1][col] = s2;
+            sStat[wp][0][wc * 32 + nt * 16 + r16] = s1;
+            sStat[wp][1][wc * 32 + nt * 16 + r16] = s2;
           }
         }
       }
     };
+    auto epilogue_s = [&](auto actf) {
+      if constexpr (swp)
+        epilogue(actf, std::integral_constant<int, 3>{});
+      else if (!do_stats)
+        epilogue(actf, std::integral_constant<int, 0>{});
+      else if (full)
+        epilogue(actf, std::integral_constant<int, 1>{});
+      else
+        epilogue(actf, std::integral_constant<int, 2>{});
+    };
+    STAMP(7);
     if (a.act == DSR_ACT_NONE)
-      epilogue([](float x) { return x; });
+      epilogue_s([](float x) { return x; });
     else if (a.act == DSR_ACT_RELU)
-      epilogue([](float x) { return x > 0.f ? x : 0.f; });
+      epilogue_s([](float x) { return vmax(x, 0.f); });
+    else if ((a.act == DSR_ACT_LEAKY || a.act == DSR_ACT_PRELU) && slope >= 0.f && slope <= 1.f)
+      epilogue_s([slope](float x) { return vmax(x, x * slope); });      // == x >= 0 ? x : x * slope for 0 <= slope <= 1
     else if (a.act == DSR_ACT_LEAKY || a.act == DSR_ACT_PRELU)
-      epilogue([slope](float x) { return x >= 0.f ? x : x * slope; });
+      epilogue_s([slope](float x) { return x >= 0.f ? x : x * slope; });
     else
-      epilogue([&](float x) { return act_apply(a.act, x, slope); });
+      epilogue_s([&](float x) { return act_apply(a.act, x, slope); });
+    STAMP(4);
     // raw barrier: a __syncthreads() here would also drain the next tile's DMA
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    STAMP(5);
     if (do_stats && tid < 128) {
       const int which = tid >> 6, col = tid & 63;
       a.stats[((size_t)t * 2 + which) * a.CoutP + c0 + col] = sStat[0][which][col] + sStat[1][which][col];
     }
-    if (!(a.flags & DSR_F_PIXSHUF)) {
+    {
+      // exactly 2 stores per thread (see the wait above).  Scalar part: byte offset of the tile origin in y.
+      const unsigned sorg = pixshuf ? (unsigned)(((n * 2 * a.H + 2 * oy0) * (2 * a.W) + 2 * ox0) * (a.CoutP / 4) * 2 + (c0 / 4) * 2)
+                                    : (unsigned)(((n * a.H + oy0) * a.W + ox0) * a.CoutP * 2 + c0 * 2);
 #pragma unroll
-      for (int it = 0; it < TR * 32 * 8 / 256; ++it) {          // exactly 2 stores per thread (see the wait above)
-        const int idx = tid + it * 256;
-        const int prow = idx >> 3, ch = idx & 7;
-        const int oy = oy0 + (prow >> 5), ox = ox0 + (prow & 31);
-        const bool ok = oy < a.H && ox < a.W;
-        const size_t off = ok ? ((size_t)(n * a.H + oy) * a.W + ox) * a.CoutP + c0 + ch * 8 : 0;
-        U4 v = *reinterpret_cast<const U4*>(sC + prow * C_STRIDE + ch * 16);
+      for (int it = 0; it < 2; ++it) {
+        U4 v = *reinterpret_cast<const U4*>(sC + cr_base + it * 32 * C_STRIDE);
+        unsigned off = sorg + (unsigned)(st_part + it * st_step);
+        if (!full) {                                                    // (uniform) ragged tile: per-lane range check
+          const int prow = (tid >> 3) + it * 32;
+          if (!(oy0 + (prow >> 5) < a.H && ox0 + (prow & 31) < a.W)) off = OOB;
+        }
         if (FOLD && (a.flags & DSR_F_RESIDUAL)) {   // skip connection (generator.py:24,74): added after the activation
           float f[8], rr[8];
           unpack8<DT>(v, f);
-          unpack8<DT>(*reinterpret_cast<const U4*>(reinterpret_cast<const unsigned short*>(a.res) + off), rr);
+          unpack8<DT>(__builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(
+                          __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res), 0, a.y_bytes, 0x00020000), off, 0, 0)), rr);
 #pragma unroll
           for (int q = 0; q < 8; ++q) f[q] += rr[q];
           v = pack8<DT>(f);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrsrc, ok ? (unsigned)(off * 2) : OOB, 0, 0);
-      }
-    } else {
-      // PixelShuffle(2): conv channel 4c + 2i + j of pixel (h, w) -> channel c of pixel (2h+i, 2w+j); this slice's 64
-      // conv channels are 16 output channels (two 8-channel vectors) of each of the 4 sub-pixels
-      const int OCp = a.CoutP / 4;
-#pragma unroll
-      for (int it = 0; it < TR * 32 * 8 / 256; ++it) {          // exactly 2 stores per thread
-        const int idx = tid + it * 256;
-        const int prow = idx >> 3, sub = (idx >> 1) & 3, cq = idx & 1;
-        const int oy = oy0 + (prow >> 5), ox = ox0 + (prow & 31);
-        const bool ok = oy < a.H && ox < a.W;
-        const unsigned short* src = reinterpret_cast<const unsigned short*>(sC + prow * C_STRIDE);
-        unsigned short v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = src[4 * (cq * 8 + q) + sub];
-        U4 o;
-        o.x = v[0] | ((unsigned)v[1] << 16);
-        o.y = v[2] | ((unsigned)v[3] << 16);
-        o.z = v[4] | ((unsigned)v[5] << 16);
-        o.w = v[6] | ((unsigned)v[7] << 16);
-        const int py = 2 * oy + (sub >> 1), px = 2 * ox + (sub & 1);
-        const size_t off = ((size_t)(n * 2 * a.H + py) * (2 * a.W) + px) * OCp + c0 / 4 + cq * 8;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, ok ? (unsigned)(off * 2) : OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrsrc, off, 0, 0);
       }
     }
+    STAMP(6);
   }
+#ifdef DSR_C64_STAMPS
+  if (blockIdx.x == 37 && blockIdx.y == 0 && (tid == 0 || tid == 192))
+    for (int q = 0; q < 8; ++q) g_c64_stamps[(tid ? 8 : 0) + q] = st_acc[q];
+#endif
 }
 
 // statistics rows written by one launch (= spatial tiles)
@@ -254,14 +448,22 @@ void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st) {
   a.x_bytes = (unsigned)((size_t)N * a.H * a.W * 128);
   a.y_bytes = (unsigned)((size_t)N * a.H * a.W * a.CoutP * 2);   // (PixelShuffle: [N][2H][2W][CoutP/4] is the same size)
   const int slices = a.CoutP / 64;                            // blockIdx.y: 64-channel slice of the output
-  const int per_slice = 512 / slices;                         // 2 resident blocks per CU over all slices
+  int per_slice = 512 / slices;                               // 2 resident blocks per CU over all slices
+#ifdef DSR_C64_STAMPS
+  if (const char* e = getenv("DSR_C64_BLOCKS")) per_slice = atoi(e) / slices;
+#endif
   dim3 grid(a.ntiles < per_slice ? a.ntiles : per_slice, slices), block(256);
   const bool fold = (a.flags & (DSR_F_AFFINE | DSR_F_RESIDUAL)) != 0;
+  const int mode = fold ? 2 : ((a.flags & DSR_F_STATS) ? 0 : 1);
+#define C64_LAUNCH(DTV, M) hipLaunchKernelGGL((conv_c64_kernel<DTV, M>), grid, block, 0, st, a)
   if (dtype == DSR_DTYPE_BF16) {
-    if (fold) hipLaunchKernelGGL((conv_c64_kernel<DSR_DTYPE_BF16, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((conv_c64_kernel<DSR_DTYPE_BF16, false>), grid, block, 0, st, a);
+    if (mode == 2) C64_LAUNCH(DSR_DTYPE_BF16, 2);
+    else if (mode == 1) C64_LAUNCH(DSR_DTYPE_BF16, 1);
+    else C64_LAUNCH(DSR_DTYPE_BF16, 0);
   } else {
-    if (fold) hipLaunchKernelGGL((conv_c64_kernel<DSR_DTYPE_F16, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((conv_c64_kernel<DSR_DTYPE_F16, false>), grid, block, 0, st, a);
+    if (mode == 2) C64_LAUNCH(DSR_DTYPE_F16, 2);
+    else if (mode == 1) C64_LAUNCH(DSR_DTYPE_F16, 1);
+    else C64_LAUNCH(DSR_DTYPE_F16, 0);
   }
+#undef C64_LAUNCH
 }

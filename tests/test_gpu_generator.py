@@ -77,6 +77,10 @@ def test_generator_train_fwd_bwd(dev, factor, nres, shape):
     ferr = (yn.detach() - yr.detach()).abs().max().item()
     assert err <= 3.0 * ferr + 0.01, (err, ferr)
     bad = []
+    # PReLU slopes: every one of these scalar gradients is a sum of the same kind of +/- terms over a whole activation
+    # map, so their storage-rounding noise scales with the typical magnitude of such a sum, not with the (possibly
+    # cancelling) individual value: the absolute term is tied to the largest of them
+    scal = max([float(osd[k].grad.abs()) for k, p in g.named_parameters() if p.numel() == 1] or [0.0])
     for k, p in g.named_parameters():
         ref = osd[k].grad
         if ref.abs().sum() < 1e-3 * max(1.0, ref.numel() ** 0.5):     # pre-BN biases: analytically zero
@@ -84,7 +88,7 @@ def test_generator_train_fwd_bwd(dev, factor, nres, shape):
         got, sim = p.grad.cpu(), nsd[k].grad
         if ref.numel() == 1:
             floor = float((sim - ref).abs())
-            if float((got - ref).abs()) > 3.0 * floor + 0.25 * float(ref.abs()):   # ill-conditioned scalar sums
+            if float((got - ref).abs()) > 3.0 * floor + 0.25 * float(ref.abs()) + 0.05 * scal:   # ill-conditioned scalar sums
                 bad.append((k, float(got), float(ref), float(sim)))
             continue
         c, cf = cos(got, ref), cos(sim, ref)
