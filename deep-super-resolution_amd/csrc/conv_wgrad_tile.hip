@@ -177,12 +177,67 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradTileA
   constexpr unsigned OOB = 0xFFFFFFF0u;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int per_img = a.tiles_y * a.tiles_x;
-  auto dma = [&](int t, int buf) {
-    const int n = t / per_img;
-    const int rem = t - n * per_img;
-    const int ty = rem / a.tiles_x;
-    const int oy0 = ty * R, ox0 = (rem - ty * a.tiles_x) * 32;
+  // Per-tile vector work of the loader is what the MFMA phase of the partner block pays for (conv_c64.hip): addresses
+  // are a tile-invariant per-lane part + one scalar per tile, image rows are range-checked by a per-image buffer
+  // resource, the column check runs only for tiles at the left / right image edge, and the tile coordinates are
+  // advanced, not divided out.  Zero padding only; reflect / replicate (DIP) keep the general per-lane mapping.
+  constexpr int NX = (HR * HC) / 32, NY = (R * 32) / 32;
+  constexpr int FAR = 0x7FFFFF00;
+  int xpart[NX], ypart[NY];
+  unsigned hc_pack = 0;
+#pragma unroll
+  for (int u = 0; u < NX; ++u) {
+    const int q = pb + 32 * u;
+    const int hr = q / HC, hc = q - hr * HC;
+    xpart[u] = (xc_ok && hc < 34) ? ((hr * a.IW + hc) * a.CinP + ci0 + chunk * 8) * 2 : FAR;
+    hc_pack |= (unsigned)hc << (6 * u);
+  }
+#pragma unroll
+  for (int u = 0; u < NY; ++u) {
+    const int p = pb + 32 * u;
+    ypart[u] = yc_ok ? (((p >> 5) * a.OW + (p & 31)) * a.CoutP + co0 + chunk * 8) * 2 : FAR;
+  }
+  const unsigned ximg = (unsigned)(a.IH * a.IW * a.CinP * 2), yimg = (unsigned)(a.OH * a.OW * a.CoutP * 2);
+  const bool fast = a.pad_mode == DSR_PAD_ZERO;
+  struct TileXY {
+    int n, ty, tx;
+  };
+  auto dma = [&](const TileXY& tc, int buf) {
+    const int n = tc.n;
+    const int oy0 = tc.ty * R, ox0 = tc.tx * 32;
     unsigned char* st = smem + buf * STAGE;
+    if (fast) {
+      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x)) + (size_t)n * ximg, 0, ximg, 0x00020000);
+      const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.dy)) + (size_t)n * yimg, 0, yimg, 0x00020000);
+      const int xs = ((oy0 - a.pad) * a.IW + ox0 - a.pad) * a.CinP * 2;       // negative above the image: out of range
+      const int ys = (oy0 * a.OW + ox0) * a.CoutP * 2;
+      unsigned char* dx = st + 8 * wave * 128;
+      if (ox0 - a.pad >= 0 && ox0 - a.pad + 34 <= a.IW) {                        // interior columns
+#pragma unroll
+        for (int u = 0; u < NX; ++u)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(dx + 32 * u * 128), 16, (unsigned)(xpart[u] + xs), 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+          const int ix = ox0 - a.pad + (int)((hc_pack >> (6 * u)) & 63);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(dx + 32 * u * 128), 16,
+                                                   (unsigned)ix < (unsigned)a.IW ? (unsigned)(xpart[u] + xs) : OOB, 0, 0, 0);
+        }
+      }
+      if (ox0 + 32 <= a.OW) {
+#pragma unroll
+        for (int u = 0; u < NY; ++u)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr)(dx + XB + 32 * u * 128), 16, (unsigned)(ypart[u] + ys), 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int u = 0; u < NY; ++u)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr)(dx + XB + 32 * u * 128), 16,
+                                                   ox0 + (pb & 31) < a.OW ? (unsigned)(ypart[u] + ys) : OOB, 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < (HR * HC) / 32; ++u) {      // 5 wave-instructions per wave: the X halo
       const int q = pb + 32 * u;
@@ -204,17 +259,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradTileA
                                                0, 0, 0);
     }
   };
+  auto next_tile = [&](TileXY c) {                   // tiles of a block are consecutive
+    if (++c.tx == a.tiles_x) {
+      c.tx = 0;
+      if (++c.ty == a.tiles_y) {
+        c.ty = 0;
+        ++c.n;
+      }
+    }
+    return c;
+  };
 
   int t = blockIdx.y * a.tiles_per_block;
   int t_end = t + a.tiles_per_block;
   if (t_end > a.ntiles) t_end = a.ntiles;
-  if (t < t_end) dma(t, 0);
+  TileXY nxt;
+  nxt.n = t / per_img;
+  nxt.ty = (t - nxt.n * per_img) / a.tiles_x;
+  nxt.tx = t - nxt.n * per_img - nxt.ty * a.tiles_x;
+  if (t < t_end) dma(nxt, 0);
   int buf = 0;
   for (; t < t_end; ++t, buf ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                    // this tile has landed; nobody still reads the other stage
     asm volatile("" ::: "memory");
-    if (t + 1 < t_end) dma(t + 1, buf ^ 1);
+    nxt = next_tile(nxt);
+    if (t + 1 < t_end) dma(nxt, buf ^ 1);
     const unsigned char* st = smem + buf * STAGE;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
