@@ -376,11 +376,53 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
   constexpr unsigned OOB = 0xFFFFFFF0u;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int per_img = a.tiles_y * a.tiles_x;
-  auto dma = [&](int t, int buf) {
-    const int n = t / per_img;
-    const int rem = t - n * per_img;
-    const int oy0 = rem / a.tiles_x, ox0 = (rem - oy0 * a.tiles_x) * 32;
+  // loader addresses as in conv_wgrad_dma_kernel: per-lane tile-invariant part + per-tile scalar (zero padding only)
+  constexpr int NX = (NSLOT + 31) / 32;           // 8 (the last pass only has slots for waves 0 and 1)
+  constexpr int FAR = 0x7FFFFF00;
+  int xpart[NX];
+  unsigned hc_lo = 0, hc_hi = 0;                  // halo column of this lane's slot in pass u, 7 bits each
+#pragma unroll
+  for (int u = 0; u < NX; ++u) {
+    const int q = pb + 32 * u;
+    const int hr = q / HC, hc = q - hr * HC;
+    xpart[u] = (xc_ok && hc < 65 && hr < HR) ? ((hr * a.IW + hc) * a.CinP + ci0 + xchunk * 8) * 2 : FAR;
+    if (u < 4) hc_lo |= (unsigned)hc << (7 * u);
+    else hc_hi |= (unsigned)hc << (7 * (u - 4));
+  }
+  const int ypart = yc_ok ? (pb * a.CoutP + co0 + ychunk * 8) * 2 : FAR;
+  const unsigned ximg = (unsigned)(a.IH * a.IW * a.CinP * 2), yimg = (unsigned)(a.OH * a.OW * a.CoutP * 2);
+  const bool fast = a.pad_mode == DSR_PAD_ZERO;
+  struct TileXY {
+    int n, ty, tx;
+  };
+  auto dma = [&](const TileXY& tc, int buf) {
+    const int n = tc.n, oy0 = tc.ty, ox0 = tc.tx * 32;
     unsigned char* st = smem + buf * STAGE;
+    if (fast) {
+      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x)) + (size_t)n * ximg, 0, ximg, 0x00020000);
+      const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.dy)) + (size_t)n * yimg, 0, yimg, 0x00020000);
+      const int ix0 = ox0 * 2 - a.pad;
+      const int xs = ((oy0 * 2 - a.pad) * a.IW + ix0) * a.CinP * 2;
+      const int ys = (oy0 * a.OW + ox0) * a.CoutP * 2;
+      unsigned char* dx = st + 8 * wave * 128;
+      const bool interior = ix0 >= 0 && ix0 + 65 <= a.IW;
+#pragma unroll
+      for (int u = 0; u < NX; ++u) {
+        if (32 * u + 8 * wave < NSLOT) {             // wave-uniform
+          unsigned off = (unsigned)(xpart[u] + xs);
+          if (!interior) {
+            const int hc = (int)(((u < 4 ? hc_lo >> (7 * u) : hc_hi >> (7 * (u - 4)))) & 127);
+            if (!((unsigned)(ix0 + hc) < (unsigned)a.IW)) off = OOB;
+          }
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(dx + 32 * u * 128), 16, off, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr)(dx + XB), 16,
+                                               (ox0 + 32 <= a.OW || ox0 + pb < a.OW) ? (unsigned)(ypart + ys) : OOB, 0, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < (NSLOT + 31) / 32; ++u) {
       if (32 * u + 8 * wave < NSLOT) {               // wave-uniform: the last pass only has slots for waves 0 and 1
@@ -406,13 +448,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
   int t = blockIdx.y * a.tiles_per_block;
   int t_end = t + a.tiles_per_block;
   if (t_end > a.ntiles) t_end = a.ntiles;
-  if (t < t_end) dma(t, 0);
+  TileXY nxt;
+  nxt.n = t / per_img;
+  nxt.ty = (t - nxt.n * per_img) / a.tiles_x;
+  nxt.tx = t - nxt.n * per_img - nxt.ty * a.tiles_x;
+  if (t < t_end) dma(nxt, 0);
   int buf = 0;
   for (; t < t_end; ++t, buf ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + 1 < t_end) dma(t + 1, buf ^ 1);
+    if (++nxt.tx == a.tiles_x) {                     // tiles of a block are consecutive
+      nxt.tx = 0;
+      if (++nxt.ty == a.tiles_y) {
+        nxt.ty = 0;
+        ++nxt.n;
+      }
+    }
+    if (t + 1 < t_end) dma(nxt, buf ^ 1);
     const unsigned char* st = smem + buf * STAGE;
     U4 fa[2];
 #pragma unroll
