@@ -571,6 +571,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
   unsigned short* __restrict__ Y = reinterpret_cast<unsigned short*>(a.y);
   if (!(a.flags & DSR_F_PIXSHUF)) {
     constexpr int CH = BN / 8;
+    // Dense output (stride-1 forward / dgrad: grid pixel m IS output pixel m) and a tile fully inside the matrix:
+    // vector idx lives at (m0 + idx / CH) * CoutP + n0 + (idx % CH) * 8 -- one scalar per tile, one per-lane constant and a
+    // scalar step per pass, instead of two magic divisions and a 64-bit address per store.
+    if (a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.GH == a.OH && a.GW == a.OW && m0 + BM <= a.M &&
+        n0 + BN <= a.CoutP && (BM * CH) % NT == 0 && (size_t)a.M * a.CoutP * 2 < 0xFFFFFF00ull) {
+      const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)((size_t)a.M * a.CoutP * 2), 0x00020000);
+      const unsigned sorg = (unsigned)(((size_t)m0 * a.CoutP + n0) * 2);
+      const unsigned lpart = (unsigned)((tid / CH) * a.CoutP * 2 + (tid % CH) * 16);
+      const unsigned step = (unsigned)((NT / CH) * a.CoutP * 2);
+      const unsigned char* src = sC + (tid / CH) * C_STRIDE + (tid % CH) * 16;
+#pragma unroll
+      for (int it = 0; it < (BM * CH) / NT; ++it) {
+        const U4 v = *reinterpret_cast<const U4*>(src + it * (NT / CH) * C_STRIDE);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), yr,
+                                               sorg + lpart + it * step, 0, 0);
+      }
+      return;
+    }
     for (int idx = tid; idx < BM * CH; idx += NT) {
       int row = idx / CH, ch = idx % CH;
       int m = m0 + row, col0 = n0 + ch * 8;
