@@ -121,6 +121,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_persist_kernel(const ConvGem
       return row * C_STRIDE + colbyte;
   };
 
+  // stride-1 output grid (forward, stride-1 dgrad): grid pixel m is output pixel m
+  const bool dense_out = a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.GH == a.OH && a.GW == a.OW;
+  const unsigned st_lpart = (unsigned)(((tid / CH) * a.CoutP + (tid % CH) * 8) * 2);
+  const unsigned st_step = (unsigned)((NT / CH) * a.CoutP * 2);
   const TapStep d0 = decode_step(0);
   int t = blockIdx.x;
   setup_tile(t);
@@ -295,7 +299,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_persist_kernel(const ConvGem
     }
 
     // ---- output stores: exactly NSTORE buffer stores per wave (masked lanes: out-of-range offset, dropped)
-    if (!(a.flags & DSR_F_PIXSHUF)) {
+    if (!(a.flags & DSR_F_PIXSHUF) && dense_out && cm0 + BM <= a.M && cn0 + BN <= a.CoutP) {
+      // dense output, tile inside the matrix: vector idx sits at (cm0 + idx / CH) * CoutP + cn0 + (idx % CH) * 8
+      const unsigned sorg = (unsigned)((cm0 * a.CoutP + cn0) * 2);
+#pragma unroll
+      for (int q = 0; q < NSTORE; ++q) {
+        const U4 v = *reinterpret_cast<const U4*>(sC + c_off(tid / CH + (NT / CH) * q, (tid % CH) * 16));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), yrsrc,
+                                               sorg + st_lpart + q * st_step, 0, 0);
+      }
+    } else if (!(a.flags & DSR_F_PIXSHUF)) {
 #pragma unroll 2
       for (int q = 0; q < NSTORE; ++q) {
         const int idx = tid + NT * q;
