@@ -28,6 +28,16 @@ def _side_stream(device):
     return _side_streams[key]
 
 
+TRACE = None    # development aid: a list -> gan_step appends (label, event recorded on the stream that reached that point)
+
+
+def _mark(label, stream):
+    if TRACE is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        TRACE.append((label, ev))
+
+
 def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g=None, sync_d=None, overlap=True):
     """train_GAN.py:38-71.  Returns (loss_D, loss_G, fake) as device tensors (no host sync here).
 
@@ -43,6 +53,7 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
     main = torch.cuda.current_stream(hr_patches.device)
     side = _side_stream(hr_patches.device) if overlap else main
     hr_feat = real_feat = None
+    _mark("start", main)
     if overlap:
         # the VGG features of the HR target depend on nothing but the batch: they run beside the generator forward
         side.wait_stream(main)
@@ -53,9 +64,11 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
             # ... and so does D's conv trunk on the real batch (:44): same weights, same BatchNorm bookkeeping order
             # (real before fake) as in the reference, just started while the generator is still running
             real_feat = disc.features(hr_patches)
+            _mark("side: HR VGG features + D(real) trunk done", side)
     gen.bn_updates = 2
     fake = gen(lr_patches)                                       # :46 and :56
     gen.bn_updates = 1
+    _mark("main: G forward done", main)
     fake_det = fake.detach()
     if overlap:
         side.wait_stream(main)                                   # `fake` is complete before D reads it
@@ -65,9 +78,11 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
         loss_d = F.bce_const(real_d, 1.0) + F.bce_const(fake_d, 0.0)  # :48, utils/GAN.py:101-105
         opt_d.zero_grad()                                        # :51 (gan_D.zero_grad())
         loss_d.backward()                                        # :52
+        _mark("D: backward done", torch.cuda.current_stream())
         if sync_d is not None:
             sync_d()
         opt_d.step()                                             # :53
+        _mark("D: Adam done", torch.cuda.current_stream())
         with torch.no_grad():
             # :58 detaches the generator output, so this D pass never sends a gradient anywhere that survives
             # (D's .grad from it is wiped by the next zero_grad, :51); it still updates D's BN running statistics.
@@ -77,6 +92,7 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
     if overlap:
         with torch.cuda.stream(side):
             loss_d, adv = d_half()
+            _mark("D half done (incl. adversarial pass)", side)
     else:
         loss_d, adv = d_half()
     # --- generator (main stream)
@@ -85,10 +101,13 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
         hr_feat.record_stream(main)
     content = perceptual.content(fake, hr_patches, hr_feat)      # the only term of :59 with a gradient path
     opt_g.zero_grad()                                            # :62
+    _mark("main: VGG content loss forward done", main)
     content.backward()                                           # :63 (d adversarial / d generator == 0, see above)
+    _mark("main: G backward done", main)
     if sync_g is not None:
         sync_g()
     opt_g.step()                                                 # :64
+    _mark("main: G Adam done", main)
     if overlap:
         main.wait_stream(side)                                   # D half done before anything later on `main`
         loss_d.record_stream(main)
