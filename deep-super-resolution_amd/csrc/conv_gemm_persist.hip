@@ -62,8 +62,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_persist_kernel(const ConvGem
   int a_iy0[RA], a_ix0[RA], a_base[RA], b_base[RB];
   auto setup_tile = [&](int t) {
     const int bid = xcd_remap(t, total);
-    const int tile_n = bid % a.tiles_n;
-    tile_m = bid / a.tiles_n;
+    int tile_n = 0;
+    tile_m = bid;
+    if (a.tiles_n != 1) {                      // (one column tile is the common case: skip the scalar division chain)
+      tile_n = bid % a.tiles_n;
+      tile_m = bid / a.tiles_n;
+    }
     m0 = tile_m * BM;
     n0 = tile_n * BN;
 #pragma unroll
