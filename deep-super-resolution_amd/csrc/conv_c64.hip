@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X_BYTES + C_BYTES + 2 * 2 * 64 * 4];
   unsigned char* sC = smem + 2 * X_BYTES;
   float (*sStat)[2][64] = reinterpret_cast<float (*)[2][64]>(smem + 2 * X_BYTES + C_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it (and what derives from it) in SGPRs
   const int g = lane >> 4, r16 = lane & 15;
   const int wp = wave >> 1, wc = wave & 1;     // tile row, channel half (32 co)
   const int c0 = blockIdx.y * 64;              // this block's slice of the output channels (Cout = 64 * gridDim.y)

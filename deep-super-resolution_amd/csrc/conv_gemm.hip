@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
   int* sTaps = reinterpret_cast<int*>(smem + LDS_BYTES + WGM * 2 * BN * 4);
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPRs (LDS-DMA base in M0 without v_readfirstlane)
   const int wm = wave / WGN, wn = wave % WGN;
   const int g = lane >> 4, r16 = lane & 15;
 

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_persist_kernel(const ConvGem
   int* sTaps = reinterpret_cast<int*>(smem + 2 * STAGE + WGM * 2 * BN * 4);
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPRs (LDS-DMA base in M0 without v_readfirstlane)
   const int wm = wave / WGN, wn = wave % WGN;
   const int g = lane >> 4, r16 = lane & 15;
   const int j = tid & 7, rb = tid >> 3;

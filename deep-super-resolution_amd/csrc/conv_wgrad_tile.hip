@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(const WgradTile
   __shared__ __attribute__((aligned(16))) unsigned char sX[HR * HC * 128];
   __shared__ __attribute__((aligned(16))) unsigned char sY[R * 32 * 128];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it (and what derives from it) in SGPRs
   const int wr = wave >> 1, wc = wave & 1;
   const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
   const int pair = blockIdx.x;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradTileA
   constexpr int XB = HR * HC * 128, YB = R * 32 * 128, STAGE = XB + YB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it (and what derives from it) in SGPRs
   const int wr = wave >> 1, wc = wave & 1;
   const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
   const int pair = blockIdx.x;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
   constexpr int XB = NSLOT * 128, YB = 32 * 128, STAGE = XB + YB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it (and what derives from it) in SGPRs
   const int wr = wave >> 1, wc = wave & 1;
   const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
   const int pair = blockIdx.x;
