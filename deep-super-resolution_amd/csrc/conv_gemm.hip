@@ -305,22 +305,27 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
           for (int k = 0; k < TN; ++k) fb[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot);
         }
         if (s + 1 < ks) dma_issue(nd, cur ^ 1);
+        // the second half-step's fragments are requested before the first half's MFMAs (a second register set): their
+        // LDS latency runs under 16 MFMAs instead of between the two MFMA groups
+        U4 fa2[TM], fb2[TN];
+        {
+          const int slot = ((4 + g) ^ sw) << 4;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa2[i] = *reinterpret_cast<const U4*>(pa + i * 16 * 128 + slot);
+#pragma unroll
+          for (int k = 0; k < TN; ++k) fb2[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int k = 0; k < TN; ++k) acc[i][k] = SWAP ? mfma16<DT>(fb[k], fa[i], acc[i][k]) : mfma16<DT>(fa[i], fb[k], acc[i][k]);
         if (s + 2 < ks) nd = decode_step(s + 2);
-        {
-          const int slot = ((4 + g) ^ sw) << 4;
-#pragma unroll
-          for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const U4*>(pa + i * 16 * 128 + slot);
-#pragma unroll
-          for (int k = 0; k < TN; ++k) fb[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot);
-        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int k = 0; k < TN; ++k) acc[i][k] = SWAP ? mfma16<DT>(fb[k], fa[i], acc[i][k]) : mfma16<DT>(fa[i], fb[k], acc[i][k]);
+          for (int k = 0; k < TN; ++k) acc[i][k] = SWAP ? mfma16<DT>(fb2[k], fa2[i], acc[i][k]) : mfma16<DT>(fa2[i], fb2[k], acc[i][k]);
       }
     } else {
       // three-stage ring, one resident block per CU: the DMA of step s+2 is issued before the MFMAs of step s, so a
