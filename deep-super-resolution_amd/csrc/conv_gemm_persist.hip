@@ -175,22 +175,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_persist_kernel(const ConvGem
         for (int k = 0; k < TN; ++k) fb[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot);
       }
       if (s + 1 < ks) dma_issue(nd, cur ^ 1);
+      // second half-step's fragments before the first half's MFMAs (second register set), as in conv_gemm.hip
+      U4 fa2[TM], fb2[TN];
+      {
+        const int slot = ((4 + g) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa2[i] = *reinterpret_cast<const U4*>(pa + i * 16 * 128 + slot);
+#pragma unroll
+        for (int k = 0; k < TN; ++k) fb2[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int k = 0; k < TN; ++k) acc[i][k] = SWAP ? mfma16<DT>(fb[k], fa[i], acc[i][k]) : mfma16<DT>(fa[i], fb[k], acc[i][k]);
       if (s + 2 < ks) nd = decode_step(s + 2);
-      {
-        const int slot = ((4 + g) ^ sw) << 4;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const U4*>(pa + i * 16 * 128 + slot);
-#pragma unroll
-        for (int k = 0; k < TN; ++k) fb[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot);
-      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int k = 0; k < TN; ++k) acc[i][k] = SWAP ? mfma16<DT>(fb[k], fa[i], acc[i][k]) : mfma16<DT>(fa[i], fb[k], acc[i][k]);
+        for (int k = 0; k < TN; ++k) acc[i][k] = SWAP ? mfma16<DT>(fb2[k], fa2[i], acc[i][k]) : mfma16<DT>(fa2[i], fb2[k], acc[i][k]);
     }
     const int L = st0 ^ ((ks - 1) & 1);                  // stage of the last K-step: becomes the C tile
     unsigned char* sC = smem + L * STAGE;
