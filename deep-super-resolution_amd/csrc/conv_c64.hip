@@ -16,6 +16,9 @@
 #include "dsr_common.h"
 #include "dsr_kernels.h"
 
+// Development aid (-DDSR_C64_STAMPS): s_memtime deltas of the phases of a tile, accumulated per wave and written at the
+// end of the kernel to a buffer of their own (dsr_debug_c64 copies it out); no output value depends on them.  The stamps
+// themselves cost ~100 cycles each, so use the build for the SPLIT between phases, not for absolute speed.
 #ifdef DSR_C64_STAMPS
 __device__ unsigned long long g_c64_stamps[16];
 extern "C" int dsr_debug_c64(unsigned long long* out) {
@@ -283,9 +286,6 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     __builtin_amdgcn_s_setprio(1);
 
     STAMP(3);
-#ifdef DSR_C64_STAMPS
-    asm volatile("v_mov_b32 %0, %0" : "+v"(acc[1][1][3]));      // first read of an accumulator: the MFMA queue has drained
-#endif
     // ---- epilogue
     const int n = cur.n;
     const int oy0 = cur.ty * TR, ox0 = cur.tx * 32;
@@ -333,10 +333,6 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
             }
             // inline asm: behind an in-flight LDS-DMA hipcc puts s_waitcnt vmcnt(0) in front of an 8-byte LDS store
             // it can see (the next tile's halo and the previous tile's output stores would be drained here)
-#ifdef DSR_C64_NOWRITE
-            asm volatile("" ::"v"(cw_lds[nt]), "v"(pk) : "memory");
-            continue;
-#endif
             if (i == 0)
               asm volatile("ds_write_b64 %0, %1" ::"v"(cw_lds[nt]), "v"(pk) : "memory");
             else
@@ -383,7 +379,6 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
       else
         epilogue(actf, std::integral_constant<int, 2>{});
     };
-    STAMP(7);
     if (a.act == DSR_ACT_NONE)
       epilogue_s([](float x) { return x; });
     else if (a.act == DSR_ACT_RELU)
