@@ -45,7 +45,7 @@ def build(dev, factor, nres, salt=0):
 
 
 @pytest.mark.parametrize("factor,nres,shape", [(4, 2, (2, 3, 24, 24)), (2, 1, (3, 3, 16, 20)), (8, 2, (1, 3, 16, 16)),
-                                               (4, 16, (2, 3, 24, 24))])
+                                               (4, 16, (2, 3, 24, 24)), (16, 1, (1, 3, 8, 12))])
 def test_generator_train_fwd_bwd(dev, factor, nres, shape):
     g, sd = build(dev, factor, nres)
     g.train()
