@@ -10,6 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libdsr_hip.so")
 
+ABI_VERSION = 2          # bumped whenever a signature in include/dsr_hip.h changes; checked against the loaded library
 BF16, F16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_PRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_ELU = range(7)
 PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = range(3)
@@ -65,6 +66,7 @@ SIGNATURES = {
     "dsr_pw_act_bwd_nchw": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dsr_pw_colsum": (_I, [_I, _P, _Z, _I, _I, _I, _P, _P]),
     "dsr_pw_add": (_I, [_I, _P, _P, _P, _Z, _P]),
+    "dsr_pw_axpby_f32": (_I, [_P, _P, _F, _F, _P, _P, _Z, _P]),
     "dsr_pw_diff_loss": (_I, [_P, _P, _P, _Z, _I, _P, _I, _P]),
     "dsr_pw_bce_const": (_I, [_P, _I, _F, _P, _P, _I, _P]),
     "dsr_pw_adam": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P, _F, _P, _P]),
@@ -109,6 +111,12 @@ def lib():
             fn = getattr(h, name)          # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        got = h.dsr_abi_version()
+        if got != ABI_VERSION:
+            # a stale libdsr_hip.so under a newer binding (or the reverse) passes arguments in the wrong slots: the
+            # kernels then read sizes as pointers -- refuse to run instead (round-1 bring-up abort)
+            raise RuntimeError(f"{SO_PATH}: C-ABI version {got}, this binding expects {ABI_VERSION}; rebuild with "
+                               "`python -c 'import __graft_entry__ as g; g.build()'`")
         _lib = h
     return _lib
 

@@ -26,7 +26,7 @@ int dsr_launch_status(const char* what) {
   return DSR_OK;
 }
 extern "C" const char* dsr_last_error(void) { return g_err; }
-extern "C" int dsr_abi_version(void) { return 1; }
+extern "C" int dsr_abi_version(void) { return 2; }
 
 static inline int r8(int c) { return (c + 7) & ~7; }
 
@@ -53,6 +53,7 @@ static int check_desc(const dsr_conv_desc* d) {
 extern "C" int dsr_conv_out_size(const dsr_conv_desc* d, int* OH, int* OW) {
   int rc = check_desc(d);
   if (rc) return rc;
+  if (!OH || !OW) return dsr_fail(DSR_E_ARG, "conv_out_size: null output pointer");
   *OH = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
   *OW = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
   return DSR_OK;
@@ -96,6 +97,7 @@ extern "C" int dsr_conv_stats_rows(const dsr_conv_desc* d) {
 }
 
 extern "C" size_t dsr_conv_packed_elems(const dsr_conv_desc* d, int dgrad) {
+  if (check_desc(d)) return 0;
   size_t T = (size_t)d->KH * d->KW;
   return dgrad ? T * r8(d->Cin) * r8(d->Cout) : T * r8(d->Cout) * r8(d->Cin);
 }
@@ -284,6 +286,7 @@ __global__ void reflect_fold_kernel(const unsigned short* __restrict__ dxp, unsi
 }
 
 extern "C" size_t dsr_conv_dgrad_workspace(const dsr_conv_desc* d) {
+  if (check_desc(d)) return 0;
   if (d->pad_mode == DSR_PAD_ZERO || d->pad == 0) return 0;
   return (size_t)d->N * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * r8(d->Cin) * 2;
 }

@@ -203,6 +203,8 @@ extern "C" int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const v
                                   float slope, float* dw, float* db, void* workspace, size_t ws_bytes, dsr_stream_t s) {
   if (!dsr_conv_first_bwd_supported(d, act)) return dsr_fail(DSR_E_UNSUPPORTED, "conv_first_bwd: unsupported layer");
   if (!x || !dout || !y || !dw) return dsr_fail(DSR_E_ARG, "conv_first_bwd: null pointer");
+  if (act == DSR_ACT_LEAKY && !(slope > 0.f))   // the derivative is read off the stored output: needs slope > 0
+    return dsr_fail(DSR_E_ARG, "conv_first_bwd: LeakyReLU slope %g must be > 0", (double)slope);
   const size_t need = dsr_conv_first_bwd_workspace(d);
   if (!workspace || ws_bytes < need) return dsr_fail(DSR_E_WORKSPACE, "conv_first_bwd: workspace %zu < %zu", ws_bytes, need);
   FirstBwdArgs a;

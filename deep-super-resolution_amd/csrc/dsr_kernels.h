@@ -166,3 +166,14 @@ void dsr_launch_wgrad_reduce(const float* partial, float* dw, int splits, int nt
 // records hipGetLastError() under `what`; returns 0 or a negative code (see dsr_last_error()).
 int dsr_launch_status(const char* what);
 int dsr_fail(int code, const char* fmt, ...);
+
+// Argument validation of the C-ABI entry points: a bad argument returns DSR_E_ARG (see dsr_last_error()) before
+// anything is launched -- a null device pointer would otherwise become a GPU memory fault, which the runtime turns
+// into an abort of the whole process.
+#define DSR_REQUIRE(cond, ...)                          \
+  do {                                                  \
+    if (!(cond)) return dsr_fail(DSR_E_ARG, __VA_ARGS__); \
+  } while (0)
+#define DSR_DTYPE_OK(dt) ((dt) == DSR_DTYPE_BF16 || (dt) == DSR_DTYPE_F16)
+// channel-chunked pointwise kernels: one thread per 8-channel chunk, 256 / (Cp / 8) pixel rows per block iteration
+#define DSR_CP_OK(Cp) ((Cp) >= 8 && (Cp) % 8 == 0 && (Cp) <= 2048)

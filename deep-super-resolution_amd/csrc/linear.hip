@@ -430,6 +430,7 @@ __global__ void dense2_bwd_kernel(const float* __restrict__ dout, const float* _
 
 // ================================================================== C ABI
 extern "C" int dsr_cast16(int dtype, const float* src, void* dst, size_t n, dsr_stream_t st) {
+  DSR_REQUIRE(src && dst && DSR_DTYPE_OK(dtype) && n > 0, "cast16: null pointer or empty");
   if (n % 8) return dsr_fail(DSR_E_ARG, "cast16: element count %zu not a multiple of 8", n);
   size_t n8 = n / 8;
   unsigned blocks = (unsigned)((n8 + 255) / 256);
@@ -443,6 +444,7 @@ extern "C" int dsr_cast16(int dtype, const float* src, void* dst, size_t n, dsr_
 
 extern "C" int dsr_flatten(int dtype, const void* src, void* dst, int B, int HW, int C, int Cp, int Bp, int mode,
                            dsr_stream_t st) {
+  DSR_REQUIRE(src && dst && DSR_DTYPE_OK(dtype) && B > 0 && HW > 0 && C > 0 && Cp >= C && mode >= 0 && mode <= 2 && (mode != 1 || Bp >= B), "flatten: null pointer or bad shape");
   if (Cp % 8) return dsr_fail(DSR_E_ARG, "flatten: Cp %% 8 != 0");
   const size_t cgroups = (size_t)(Cp + 63) / 64;
   const size_t waves = mode == 1 ? (size_t)HW * ((Bp + 63) / 64) * cgroups : (size_t)B * ((HW + 63) / 64) * cgroups;
@@ -476,6 +478,7 @@ extern "C" size_t dsr_linear_fwd_workspace(int B, size_t K, int O) {
 
 extern "C" int dsr_linear_fwd(int dtype, const void* x, const void* w16, const float* bias, int act, float slope,
                               float* out, int B, size_t K, int O, void* workspace, size_t ws_bytes, dsr_stream_t st) {
+  DSR_REQUIRE(x && w16 && out && DSR_DTYPE_OK(dtype) && K > 0 && O > 0, "linear_fwd: null pointer or bad shape");
   if (B < 1 || B > 64) return dsr_fail(DSR_E_UNSUPPORTED, "linear: batch %d outside 1..64", B);
   if (K % 8) return dsr_fail(DSR_E_ARG, "linear: K %% 8 != 0");
   size_t ch;
@@ -499,6 +502,7 @@ extern "C" int dsr_linear_fwd(int dtype, const void* x, const void* w16, const f
 
 extern "C" int dsr_linear_dgrad(int dtype, const void* dy16, const void* w16, void* dx, int B, int O, size_t K,
                                 dsr_stream_t st) {
+  DSR_REQUIRE(dy16 && w16 && dx && DSR_DTYPE_OK(dtype) && K > 0 && O > 0, "linear_dgrad: null pointer or bad shape");
   if (B < 1 || B > 64) return dsr_fail(DSR_E_UNSUPPORTED, "linear: batch %d outside 1..64", B);
   if (K % 8 || O % 8) return dsr_fail(DSR_E_ARG, "linear_dgrad: K %% 8 or O %% 8");
   dim3 grid((unsigned)((K + 127) / 128)), block(256);
@@ -517,6 +521,7 @@ extern "C" int dsr_linear_dgrad(int dtype, const void* dy16, const void* w16, vo
 
 extern "C" int dsr_linear_wgrad(int dtype, const void* dyT16, const void* xT16, float* dw, int Bp, int O, size_t K,
                                 dsr_stream_t st) {
+  DSR_REQUIRE(dyT16 && xT16 && dw && DSR_DTYPE_OK(dtype) && K > 0 && O > 0, "linear_wgrad: null pointer or bad shape");
   if (Bp != 32 && Bp != 64) return dsr_fail(DSR_E_UNSUPPORTED, "linear_wgrad: padded batch must be 32 or 64");
   if (K % 4) return dsr_fail(DSR_E_ARG, "linear_wgrad: K %% 4");
   const int tpb = 16;   // 32-wide k tiles per block -> 512 k per block
@@ -536,6 +541,7 @@ extern "C" int dsr_linear_wgrad(int dtype, const void* dyT16, const void* xT16, 
 
 extern "C" int dsr_linear_wgrad_gathered(int dtype, const void* dyT16_all, const void* xT16_all, float* dw, int Bp, int O,
                                          size_t K, int R, float scale, dsr_stream_t st) {
+  DSR_REQUIRE(dyT16_all && xT16_all && dw && DSR_DTYPE_OK(dtype) && K > 0 && O > 0, "linear_wgrad_gathered: null pointer or bad shape");
   if (Bp != 32 && Bp != 64) return dsr_fail(DSR_E_UNSUPPORTED, "linear_wgrad_gathered: padded batch must be 32 or 64");
   if (R < 1) return dsr_fail(DSR_E_ARG, "linear_wgrad_gathered: R < 1");
   const int tpb = 16;
@@ -556,6 +562,7 @@ extern "C" int dsr_linear_wgrad_gathered(int dtype, const void* dyT16_all, const
 
 extern "C" int dsr_dense2_fwd(const float* h, const float* w2, const float* b2, int B, int K1, float* out,
                               dsr_stream_t st) {
+  DSR_REQUIRE(h && w2 && out && B > 0 && K1 > 0, "dense2_fwd: null pointer or bad shape");
   hipLaunchKernelGGL(dense2_fwd_kernel, dim3(B), dim3(256), 0, st, h, w2, b2, K1, out);
   return dsr_launch_status("dsr_dense2_fwd");
 }
@@ -563,6 +570,7 @@ extern "C" int dsr_dense2_fwd(const float* h, const float* w2, const float* b2, 
 extern "C" int dsr_dense2_bwd(int dtype, const float* dout, const float* out, const float* h, const float* w2, int B,
                               int K1, int Bp, float slope, float* dw2, float* db2, float* db1, void* dy16, void* dyT16,
                               dsr_stream_t st) {
+  DSR_REQUIRE(dout && out && h && w2 && dw2 && db2 && db1 && dy16 && dyT16 && DSR_DTYPE_OK(dtype) && B > 0 && K1 > 0 && Bp >= B, "dense2_bwd: null pointer or bad shape");
   dim3 grid((K1 + 127) / 128), block(128);
   if (dtype == DSR_BF16)
     hipLaunchKernelGGL((dense2_bwd_kernel<DSR_DTYPE_BF16>), grid, block, 0, st, dout, out, h, w2, B, K1, Bp, slope, dw2,

@@ -527,6 +527,12 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const unsigned short* __re
   const int rpi = 256 / cpr;
   const int ch = tid % cpr, rr = tid / cpr;
   const float slope = prelu ? prelu[0] : slope_v;
+  // The sign of the pre-activation is read off the stored OUTPUT, which is only possible for a positive slope (with
+  // slope <= 0 both branches of PReLU / LeakyReLU give outputs of one sign).  A learned PReLU slope that has crossed
+  // zero must not produce silently wrong gradients: every gradient of this launch becomes NaN instead, which the
+  // losses / parameters show on the next step (functional.check_prelu_slopes() names the offending module).
+  const bool lin = act == DSR_ACT_LEAKY || act == DSR_ACT_PRELU;
+  const float poison = (lin && !(slope > 0.f)) ? __uint_as_float(0x7fc00000u) : 0.f;
   float sb[8], sp[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) sb[k] = sp[k] = 0.f;
@@ -562,7 +568,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const unsigned short* __re
       float g[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        g[k] = d[k] * act_grad_from_out(act, o[k], slope);
+        g[k] = d[k] * act_grad_from_out(act, o[k], slope) + poison;
         sb[k] += g[k];
         if (act == DSR_ACT_PRELU && o[k] < 0.f) sp[k] += d[k] * (o[k] / slope);
       }
@@ -656,6 +662,17 @@ __global__ void add_kernel(const unsigned short* __restrict__ a, const unsigned 
 #pragma unroll
   for (int k = 0; k < 8; ++k) x[k] += y[k];
   *reinterpret_cast<U4*>(out + idx * 8) = pack8<DT>(x);
+}
+
+// out[i] = (a * x[i] + b * y[i]) * g[0]     fp32; y and g optional (y == nullptr -> 0, g == nullptr -> 1).
+// The scalar glue of the step recipes (loss sums of utils/GAN.py:105,122, loss-gradient scaling by autograd's
+// incoming scalar, the static loss scale of the fp16 DIP path) stays on the HIP path with this one kernel.
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float a,
+                                                    float b, const float* __restrict__ g, float* __restrict__ out,
+                                                    size_t n) {
+  const float gs = g ? g[0] : 1.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = (a * x[i] + (y ? b * y[i] : 0.f)) * gs;
 }
 
 // ------------------------------------------------------------------ losses (fp32 NCHW, mean reduction)
@@ -784,12 +801,14 @@ __global__ void incr_kernel(int* step) { *step += 1; }
 static inline unsigned nblk(size_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 extern "C" int dsr_pw_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int Cp, hipStream_t st) {
+  DSR_REQUIRE(src && dst && DSR_DTYPE_OK(dtype) && N > 0 && C > 0 && H > 0 && W > 0 && Cp % 8 == 0 && Cp >= C, "nchw_to_nhwc: null pointer, empty shape or bad channel padding");
   size_t total = (size_t)N * H * W * (Cp / 8);
   DT_SWITCH(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<DT>), dim3(nblk(total, 256)), dim3(256), 0, st, src,
                                       (unsigned short*)dst, N, C, H, W, Cp));
   return dsr_launch_status("dsr_pw_nchw_to_nhwc");
 }
 extern "C" int dsr_pw_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int H, int W, int Cp, hipStream_t st) {
+  DSR_REQUIRE(src && dst && DSR_DTYPE_OK(dtype) && N > 0 && C > 0 && H > 0 && W > 0 && Cp % 8 == 0 && Cp >= C, "nhwc_to_nchw: null pointer, empty shape or bad channel padding");
   size_t total = (size_t)N * C * H * W;
   DT_SWITCH(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<DT>), dim3(nblk(total, 256)), dim3(256), 0, st,
                                       (const unsigned short*)src, dst, N, C, H, W, Cp));
@@ -797,6 +816,7 @@ extern "C" int dsr_pw_nhwc_to_nchw(int dtype, const void* src, float* dst, int N
 }
 extern "C" int dsr_pw_pack_weight(int dtype, const float* w, void* wf, void* wd, int Cout, int Cin, int T, int NBo, int CinP,
                         int NBi, int CoutP, hipStream_t st) {
+  DSR_REQUIRE(w && wf && DSR_DTYPE_OK(dtype) && Cout > 0 && Cin > 0 && T > 0 && NBo >= Cout && CinP >= Cin, "pack_weight: null pointer or bad shape");
   size_t nf = (size_t)T * NBo * CinP, nd = wd ? (size_t)T * NBi * CoutP : 0;
   size_t total = nf > nd ? nf : nd;
   DT_SWITCH(dtype, hipLaunchKernelGGL((pack_weight_kernel<DT>), dim3(nblk(total, 256)), dim3(256), 0, st, w,
@@ -806,6 +826,7 @@ extern "C" int dsr_pw_pack_weight(int dtype, const float* w, void* wf, void* wd,
 extern "C" int dsr_pw_scratch_rows(void) { return DSR_COMPACT_ROWS; }
 extern "C" int dsr_pw_sum_rows(const float* partial, int rows, int row_stride, int col_offset, int C, float scale, float* out,
                      int accumulate, int compact, hipStream_t st) {
+  DSR_REQUIRE(partial && out && rows >= 0 && row_stride > 0 && col_offset >= 0 && C > 0, "sum_rows: null pointer or bad shape");
   if (compact && row_stride > 1) partial = compact_rows(partial, rows, row_stride, &rows, st);
   hipLaunchKernelGGL(sum_rows_kernel, dim3(nblk(C, 128)), dim3(128), 0, st, partial, rows, row_stride, col_offset, C,
                      scale, out, accumulate);
@@ -814,6 +835,7 @@ extern "C" int dsr_pw_sum_rows(const float* partial, int rows, int row_stride, i
 extern "C" int dsr_pw_bn_finalize(const float* partial, int tiles, int stride, int C, int Cp, float count, const float* gamma,
                         const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, int updates,
                         float* scale, float* shift, float* mean, float* rstd, hipStream_t st) {
+  DSR_REQUIRE(partial && gamma && beta && scale && shift && mean && rstd && tiles > 0 && C > 0 && Cp >= C && stride >= Cp && count > 0.f && updates >= 0, "bn_finalize: null pointer or bad shape");
   partial = compact_rows(partial, tiles, 2 * stride, &tiles, st);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(Cp, 64)), dim3(64), 0, st, partial, tiles, stride, C, count, gamma,
                      beta, rm, rv, nbt, momentum, eps, updates, scale, shift, mean, rstd, Cp);
@@ -821,11 +843,13 @@ extern "C" int dsr_pw_bn_finalize(const float* partial, int tiles, int stride, i
 }
 extern "C" int dsr_pw_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
                            int Cp, float* scale, float* shift, float* mean, float* rstd, hipStream_t st) {
+  DSR_REQUIRE(gamma && beta && rm && rv && scale && shift && C > 0 && Cp >= C, "bn_eval_affine: null pointer or bad shape");
   hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(nblk(Cp, 128)), dim3(128), 0, st, gamma, beta, rm, rv, eps, C, Cp,
                      scale, shift, mean, rstd);
   return dsr_launch_status("dsr_pw_bn_eval_affine");
 }
 extern "C" int dsr_pw_reduce_blocks(size_t P, int* rows_per_block) {
+  if (!rows_per_block) return dsr_fail(DSR_E_ARG, "reduce_blocks: null rows_per_block");
   // enough blocks to fill 256 CUs a few times over, at least 64 rows each
   size_t target = 2048;
   size_t rpb = (P + target - 1) / target;
@@ -835,12 +859,15 @@ extern "C" int dsr_pw_reduce_blocks(size_t P, int* rows_per_block) {
 }
 extern "C" int dsr_pw_channel_stats(int dtype, const void* x, size_t P, int Cp, int blocks, int rpb, float* partial,
                           hipStream_t st) {
+  DSR_REQUIRE(x && partial && DSR_DTYPE_OK(dtype) && P > 0 && DSR_CP_OK(Cp) && blocks > 0 && rpb > 0, "channel_stats: null pointer or bad shape");
   DT_SWITCH(dtype, hipLaunchKernelGGL((channel_stats_kernel<DT>), dim3(blocks), dim3(256), 0, st,
                                       (const unsigned short*)x, P, Cp, rpb, partial));
   return dsr_launch_status("dsr_pw_channel_stats");
 }
 extern "C" int dsr_pw_bn_act_fwd(int dtype, const void* y, const float* scale, const float* shift, const void* residual, void* out,
                        size_t P, int Cp, int act, float slope, const float* prelu, hipStream_t st) {
+  DSR_REQUIRE(y && out && DSR_DTYPE_OK(dtype) && P > 0 && DSR_CP_OK(Cp) && (!scale == !shift), "bn_act_fwd: null pointer or bad shape");
+  DSR_REQUIRE(act != DSR_ACT_PRELU || prelu, "bn_act_fwd: PReLU needs its weight pointer");
   const int rpi = 256 / (Cp / 8);
   size_t want = (P + (size_t)rpi * 8 - 1) / ((size_t)rpi * 8);     // >= 8 pixels per thread amortise the parameter loads
   unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
@@ -852,6 +879,8 @@ extern "C" int dsr_pw_bn_act_fwd(int dtype, const void* y, const float* scale, c
 extern "C" int dsr_pw_bn_act_bwd_reduce(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
                               const float* mean, const float* rstd, size_t P, int Cp, int blocks, int rpb, int act,
                               float slope, const float* prelu, float* partial, hipStream_t st) {
+  DSR_REQUIRE(dout && y && scale && shift && mean && rstd && partial && DSR_DTYPE_OK(dtype) && P > 0 && DSR_CP_OK(Cp) && blocks > 0 && rpb > 0, "bn_act_bwd_reduce: null pointer or bad shape");
+  DSR_REQUIRE(act != DSR_ACT_PRELU || prelu, "bn_act_bwd_reduce: PReLU needs its weight pointer");
   DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DT>), dim3(blocks), dim3(256), 0, st,
                                       (const unsigned short*)dout, (const unsigned short*)y, scale, shift, mean, rstd, P,
                                       Cp, rpb, act, slope, prelu, partial));
@@ -859,6 +888,7 @@ extern "C" int dsr_pw_bn_act_bwd_reduce(int dtype, const void* dout, const void*
 }
 extern "C" int dsr_pw_bn_bwd_finalize(const float* partial, int blocks, int C, int Cp, float count, float* dgamma, float* dbeta,
                             float* dprelu, float* c1, float* c2, hipStream_t st) {
+  DSR_REQUIRE(partial && c1 && c2 && blocks > 0 && C > 0 && Cp >= C && count > 0.f, "bn_bwd_finalize: null pointer or bad shape");
   partial = compact_rows(partial, blocks, 3 * Cp, &blocks, st);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, blocks, C, Cp, count, dgamma, dbeta,
                      dprelu, c1, c2);
@@ -867,6 +897,8 @@ extern "C" int dsr_pw_bn_bwd_finalize(const float* partial, int blocks, int C, i
 extern "C" int dsr_pw_bn_act_bwd_apply(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
                              const float* mean, const float* rstd, const float* c1, const float* c2, void* dy, size_t P,
                              int Cp, int act, float slope, const float* prelu, int train, hipStream_t st) {
+  DSR_REQUIRE(dout && y && scale && shift && mean && rstd && dy && (!train || (c1 && c2)) && DSR_DTYPE_OK(dtype) && P > 0 && DSR_CP_OK(Cp), "bn_act_bwd_apply: null pointer or bad shape");
+  DSR_REQUIRE(act != DSR_ACT_PRELU || prelu, "bn_act_bwd_apply: PReLU needs its weight pointer");
   const int rpi = 256 / (Cp / 8);
   size_t want = (P + (size_t)rpi * 8 - 1) / ((size_t)rpi * 8);
   unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
@@ -878,6 +910,10 @@ extern "C" int dsr_pw_bn_act_bwd_apply(int dtype, const void* dout, const void* 
 extern "C" int dsr_pw_act_bwd(int dtype, const void* dout, const void* out, void* dy, int N, int H, int W, int CyP, int CoP,
                     int pixshuf, int act, float slope, const float* prelu, int blocks, int rpb, float* partial,
                     hipStream_t st) {
+  DSR_REQUIRE(dout && out && dy && DSR_DTYPE_OK(dtype) && N > 0 && H > 0 && W > 0 && DSR_CP_OK(CyP) && CoP > 0 && CoP % 2 == 0 && blocks > 0 && rpb > 0, "act_bwd: null pointer or bad shape");
+  DSR_REQUIRE(act != DSR_ACT_PRELU || prelu, "act_bwd: PReLU needs its weight pointer");
+  // the derivative is taken from the stored OUTPUT, which identifies the branch only for a positive slope
+  DSR_REQUIRE(act != DSR_ACT_LEAKY || slope > 0.f, "act_bwd: LeakyReLU slope %g must be > 0 (the activation gradient is derived from the stored output)", (double)slope);
   DT_SWITCH(dtype, hipLaunchKernelGGL((act_bwd_kernel<DT>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dout,
                                       (const unsigned short*)out, (unsigned short*)dy, N, H, W, CyP, CoP, pixshuf, act,
                                       slope, prelu, rpb, partial));
@@ -885,33 +921,46 @@ extern "C" int dsr_pw_act_bwd(int dtype, const void* dout, const void* out, void
 }
 extern "C" int dsr_pw_act_bwd_nchw(int dtype, const float* dout, const float* out, void* dy, int N, int C, int H, int W, int Cp,
                          int act, hipStream_t st) {
+  DSR_REQUIRE(dout && out && dy && DSR_DTYPE_OK(dtype) && N > 0 && C > 0 && H > 0 && W > 0 && Cp % 8 == 0 && Cp >= C, "act_bwd_nchw: null pointer or bad shape");
   size_t P = (size_t)N * H * W;
   DT_SWITCH(dtype, hipLaunchKernelGGL((act_bwd_nchw_kernel<DT>), dim3(nblk(P, 256)), dim3(256), 0, st, dout, out,
                                       (unsigned short*)dy, N, C, H, W, Cp, act));
   return dsr_launch_status("dsr_pw_act_bwd_nchw");
 }
 extern "C" int dsr_pw_colsum(int dtype, const void* x, size_t P, int Cp, int blocks, int rpb, float* partial, hipStream_t st) {
+  DSR_REQUIRE(x && partial && DSR_DTYPE_OK(dtype) && P > 0 && DSR_CP_OK(Cp) && blocks > 0 && rpb > 0, "colsum: null pointer or bad shape");
   DT_SWITCH(dtype, hipLaunchKernelGGL((colsum_kernel<DT>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)x, P,
                                       Cp, rpb, partial));
   return dsr_launch_status("dsr_pw_colsum");
 }
 extern "C" int dsr_pw_add(int dtype, const void* a, const void* b, void* out, size_t nvec, hipStream_t st) {
+  DSR_REQUIRE(a && b && out && DSR_DTYPE_OK(dtype) && nvec > 0, "add: null pointer or empty");
   DT_SWITCH(dtype, hipLaunchKernelGGL((add_kernel<DT>), dim3(nblk(nvec, 256)), dim3(256), 0, st,
                                       (const unsigned short*)a, (const unsigned short*)b, (unsigned short*)out, nvec));
   return dsr_launch_status("dsr_pw_add");
 }
+extern "C" int dsr_pw_axpby_f32(const float* x, const float* y, float a, float b, const float* g, float* out, size_t n,
+                                hipStream_t st) {
+  DSR_REQUIRE(x && out && n > 0, "axpby_f32: null pointer or empty");
+  size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)(want > 4096 ? 4096 : want)), dim3(256), 0, st, x, y, a, b, g, out, n);
+  return dsr_launch_status("dsr_pw_axpby_f32");
+}
 extern "C" int dsr_pw_diff_loss(const float* pred, const float* tgt, float* grad, size_t n, int mode, float* partial, int blocks,
                       hipStream_t st) {
+  DSR_REQUIRE(pred && tgt && partial && n > 0 && blocks > 0 && (mode == 0 || mode == 1), "diff_loss: null pointer, empty tensor or bad mode");
   hipLaunchKernelGGL(diff_loss_kernel, dim3(blocks), dim3(256), 0, st, pred, tgt, grad, n, mode, 1.f / (float)n,
                      partial);
   return dsr_launch_status("dsr_pw_diff_loss");
 }
 extern "C" int dsr_pw_bce_const(const float* p, int n, float target, float* loss, float* grad, int accumulate, hipStream_t st) {
+  DSR_REQUIRE(p && loss && n > 0, "bce_const: null pointer or empty");
   hipLaunchKernelGGL(bce_const_kernel, dim3(1), dim3(256), 0, st, p, n, target, loss, grad, accumulate);
   return dsr_launch_status("dsr_pw_bce_const");
 }
 extern "C" int dsr_pw_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                  const int* step, float grad_scale, void* shadow_bf16, hipStream_t st) {
+  DSR_REQUIRE(p && g && m && v && step && n > 0, "adam: null pointer or empty tensor");
   size_t want = (n / 4 + 511) / 512;
   unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 65536 ? 65536 : want));
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, step, grad_scale,
@@ -978,6 +1027,7 @@ extern "C" int dsr_pw_adam_multi(int count, float* const* p, const float* const*
   return dsr_launch_status("dsr_pw_adam_multi");
 }
 extern "C" int dsr_pw_incr(int* step, hipStream_t st) {
+  DSR_REQUIRE(step, "incr: null pointer");
   hipLaunchKernelGGL(incr_kernel, dim3(1), dim3(1), 0, st, step);
   return dsr_launch_status("dsr_pw_incr");
 }

@@ -387,6 +387,8 @@ __global__ void downsample_bwd_kernel(const float* __restrict__ dy, const float*
 static inline unsigned nb(size_t n) { return (unsigned)((n + 255) / 256); }
 
 extern "C" int dsr_maxpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t st) {
+  DSR_REQUIRE(x && y && DSR_DTYPE_OK(dtype) && N > 0 && H > 0 && W > 0 && Cp >= 8 && Cp % 8 == 0, "maxpool2_fwd: null pointer or bad shape");
+  DSR_REQUIRE(H >= 2 && W >= 2, "maxpool2_fwd: input smaller than the 2x2 window");
   size_t total = (size_t)N * (H / 2) * (W / 2) * (Cp / 8);
   DT_SWITCH2(dtype, hipLaunchKernelGGL((maxpool2_fwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
                                        (const unsigned short*)x, (unsigned short*)y, N, H, W, Cp));
@@ -394,6 +396,7 @@ extern "C" int dsr_maxpool2_fwd(int dtype, const void* x, void* y, int N, int H,
 }
 extern "C" int dsr_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int Cp,
                                 dsr_stream_t st) {
+  DSR_REQUIRE(x && dy && dx && DSR_DTYPE_OK(dtype) && N > 0 && H >= 2 && W >= 2 && Cp >= 8 && Cp % 8 == 0, "maxpool2_bwd: null pointer or bad shape");
   size_t total = (size_t)N * H * W * (Cp / 8);
   DT_SWITCH2(dtype, hipLaunchKernelGGL((maxpool2_bwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
                                        (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, N, H, W,
@@ -401,6 +404,7 @@ extern "C" int dsr_maxpool2_bwd(int dtype, const void* x, const void* dy, void* 
   return dsr_launch_status("dsr_maxpool2_bwd");
 }
 extern "C" int dsr_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t st) {
+  DSR_REQUIRE(x && y && DSR_DTYPE_OK(dtype) && N > 0 && H > 0 && W > 0 && Cp >= 8 && Cp % 8 == 0, "avgpool2_fwd: null pointer or bad shape");
   size_t total = (size_t)N * (H / 2) * (W / 2) * (Cp / 8);
   if (total == 0) return 0;
   DT_SWITCH2(dtype, hipLaunchKernelGGL((avgpool2_fwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
@@ -408,6 +412,7 @@ extern "C" int dsr_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H,
   return dsr_launch_status("dsr_avgpool2_fwd");
 }
 extern "C" int dsr_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, dsr_stream_t st) {
+  DSR_REQUIRE(dy && dx && DSR_DTYPE_OK(dtype) && N > 0 && H > 0 && W > 0 && Cp >= 8 && Cp % 8 == 0, "avgpool2_bwd: null pointer or bad shape");
   size_t total = (size_t)N * H * W * (Cp / 8);
   if (total == 0) return 0;
   DT_SWITCH2(dtype, hipLaunchKernelGGL((avgpool2_bwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
@@ -415,6 +420,7 @@ extern "C" int dsr_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int 
   return dsr_launch_status("dsr_avgpool2_bwd");
 }
 extern "C" int dsr_nearest2x_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t st) {
+  DSR_REQUIRE(x && y && DSR_DTYPE_OK(dtype) && N > 0 && H > 0 && W > 0 && Cp >= 8 && Cp % 8 == 0, "nearest2x_fwd: null pointer or bad shape");
   size_t total = (size_t)N * 4 * H * W * (Cp / 8);
   if (total == 0) return 0;
   DT_SWITCH2(dtype, hipLaunchKernelGGL((nearest2x_fwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
@@ -422,6 +428,7 @@ extern "C" int dsr_nearest2x_fwd(int dtype, const void* x, void* y, int N, int H
   return dsr_launch_status("dsr_nearest2x_fwd");
 }
 extern "C" int dsr_nearest2x_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, dsr_stream_t st) {
+  DSR_REQUIRE(dy && dx && DSR_DTYPE_OK(dtype) && N > 0 && H > 0 && W > 0 && Cp >= 8 && Cp % 8 == 0, "nearest2x_bwd: null pointer or bad shape");
   size_t total = (size_t)N * H * W * (Cp / 8);
   if (total == 0) return 0;
   DT_SWITCH2(dtype, hipLaunchKernelGGL((nearest2x_bwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
@@ -429,12 +436,14 @@ extern "C" int dsr_nearest2x_bwd(int dtype, const void* dy, void* dx, int N, int
   return dsr_launch_status("dsr_nearest2x_bwd");
 }
 extern "C" int dsr_bilinear2x_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t st) {
+  DSR_REQUIRE(x && y && DSR_DTYPE_OK(dtype) && N > 0 && H > 0 && W > 0 && Cp >= 8 && Cp % 8 == 0, "bilinear2x_fwd: null pointer or bad shape");
   size_t total = (size_t)N * 4 * H * W * (Cp / 8);
   DT_SWITCH2(dtype, hipLaunchKernelGGL((bilinear2x_fwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
                                        (const unsigned short*)x, (unsigned short*)y, N, H, W, Cp));
   return dsr_launch_status("dsr_bilinear2x_fwd");
 }
 extern "C" int dsr_bilinear2x_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, dsr_stream_t st) {
+  DSR_REQUIRE(dy && dx && DSR_DTYPE_OK(dtype) && N > 0 && H > 0 && W > 0 && Cp >= 8 && Cp % 8 == 0, "bilinear2x_bwd: null pointer or bad shape");
   size_t total = (size_t)N * H * W * (Cp / 8);
   DT_SWITCH2(dtype, hipLaunchKernelGGL((bilinear2x_bwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
                                        (const unsigned short*)dy, (unsigned short*)dx, N, H, W, Cp));
@@ -443,6 +452,7 @@ extern "C" int dsr_bilinear2x_bwd(int dtype, const void* dy, void* dx, int N, in
 extern "C" int dsr_resize_norm_fwd(int dtype, const float* src, void* dst, int N, int C, int H, int W, int OH, int OW,
                                    const int* ys, const int* yc, const float* yw, const int* xs, const int* xc,
                                    const float* xw, int KT, const float* mean3, const float* std3, dsr_stream_t st) {
+  DSR_REQUIRE(src && dst && ys && yc && yw && xs && xc && xw && mean3 && std3 && DSR_DTYPE_OK(dtype) && N > 0 && C > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && KT > 0, "resize_norm_fwd: null pointer or bad shape");
   if (C > 3) return dsr_fail(DSR_E_UNSUPPORTED, "resize_norm: C %d > 3", C);
   size_t total = (size_t)N * OH * OW;
   DT_SWITCH2(dtype, hipLaunchKernelGGL((resize_norm_fwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st, src,
@@ -453,6 +463,7 @@ extern "C" int dsr_resize_norm_fwd(int dtype, const float* src, void* dst, int N
 extern "C" int dsr_resize_norm_bwd(int dtype, const void* dout, float* dsrc, int N, int C, int H, int W, int OH, int OW,
                                    const int* ty_s, const int* ty_c, const float* ty_w, const int* tx_s,
                                    const int* tx_c, const float* tx_w, int KT, const float* std3, dsr_stream_t st) {
+  DSR_REQUIRE(dout && dsrc && ty_s && ty_c && ty_w && tx_s && tx_c && tx_w && std3 && DSR_DTYPE_OK(dtype) && N > 0 && C > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && KT > 0, "resize_norm_bwd: null pointer or bad shape");
   if (C > 3) return dsr_fail(DSR_E_UNSUPPORTED, "resize_norm: C %d > 3", C);
   size_t total = (size_t)N * H * W;
   DT_SWITCH2(dtype, hipLaunchKernelGGL((resize_norm_bwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
@@ -462,6 +473,7 @@ extern "C" int dsr_resize_norm_bwd(int dtype, const void* dout, float* dsrc, int
 }
 extern "C" int dsr_box_copy(const void* src, void* dst, int N, int BH, int BW, int C, int SH, int SW, int SCp, int sy0,
                             int sx0, int cs0, int DH, int DW, int DCp, int dy0, int dx0, int cd0, dsr_stream_t st) {
+  DSR_REQUIRE(src && dst && N > 0 && BH > 0 && BW > 0 && C > 0 && cs0 >= 0 && cd0 >= 0, "box_copy: null pointer or empty box");
   if (sy0 < 0 || sx0 < 0 || dy0 < 0 || dx0 < 0 || sy0 + BH > SH || sx0 + BW > SW || dy0 + BH > DH || dx0 + BW > DW ||
       cs0 + C > SCp || cd0 + C > DCp)
     return dsr_fail(DSR_E_ARG, "box_copy: box outside a tensor");
@@ -472,6 +484,7 @@ extern "C" int dsr_box_copy(const void* src, void* dst, int N, int BH, int BW, i
 }
 extern "C" int dsr_downsample_fwd(const float* x, const float* kern, float* y, int NC, int H, int W, int k, int f,
                                   int p, dsr_stream_t st) {
+  DSR_REQUIRE(x && kern && y && NC > 0 && H > 0 && W > 0 && k > 0 && f > 0 && p >= 0, "downsample_fwd: null pointer or bad shape");
   int OH = (H + 2 * p - k) / f + 1, OW = (W + 2 * p - k) / f + 1;
   if (OH < 1 || OW < 1) return dsr_fail(DSR_E_ARG, "downsample: empty output");
   size_t total = (size_t)NC * OH * OW;
@@ -480,6 +493,7 @@ extern "C" int dsr_downsample_fwd(const float* x, const float* kern, float* y, i
 }
 extern "C" int dsr_downsample_bwd(const float* dy, const float* kern, float* dx, int NC, int H, int W, int k, int f,
                                   int p, dsr_stream_t st) {
+  DSR_REQUIRE(dy && kern && dx && NC > 0 && H > 0 && W > 0 && k > 0 && f > 0 && p >= 0 && H + 2 * p >= k && W + 2 * p >= k, "downsample_bwd: null pointer or bad shape");
   int OH = (H + 2 * p - k) / f + 1, OW = (W + 2 * p - k) / f + 1;
   size_t total = (size_t)NC * H * W;
   hipLaunchKernelGGL(downsample_bwd_kernel, dim3(nb(total)), dim3(256), 0, st, dy, kern, dx, NC, H, W, OH, OW, k, f, p);

@@ -1,0 +1,74 @@
+"""Checkpoint interchange and the generator evaluation loop on the HIP path.
+
+Counterparts of the reference's host glue, kept format-compatible so that ``.pth`` files move both ways:
+  save_model / load_model      utils/common.py:11-18, 46-60  (``torch.save(model.state_dict())``; ``module.`` prefix of a
+                               DataParallel/DDP-wrapped model stripped on load)
+  evaluate_generator           eval_GAN.py:21-69  (``gan_G.eval()``, one image at a time, PSNR average, PNG dump) --
+                               run under ``no_grad`` and optionally halo-tiled (infer.super_resolve), which the reference's
+                               loop lacks (its images are pre-shrunk "because too big for the forward pass", dataset.py:21-23)
+
+PSNR is 10*log10(range^2 / MSE) (torchmetrics' definition; that package is absent here, so the formula is restated --
+"parity unpinned").  ``data_range=None`` infers max-min of the target like ``PeakSignalNoiseRatio()`` does.
+The MSE is reduced on the device by the HIP loss kernel; only the final scalar crosses to the host.
+"""
+import math
+import os
+from collections import OrderedDict
+
+import torch
+
+from . import functional as F
+from . import infer
+
+
+def save_model(model, name, out_dir):
+    """utils/common.py:11-18: <out_dir>/<name>.pth holding model.state_dict() (tensors moved to the host so that the file
+    loads anywhere)."""
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, f"{name}.pth")
+    torch.save(OrderedDict((k, v.detach().cpu()) for k, v in model.state_dict().items()), path)
+    return path
+
+
+def load_model(model, model_path):
+    """utils/common.py:46-60: load a reference-format checkpoint, with or without the ``module.`` key prefix.
+    ``weights_only=True`` (as in the reference): nothing in the file is executed."""
+    state = torch.load(model_path, map_location="cpu", weights_only=True)
+    clean = OrderedDict((k[len("module."):] if k.startswith("module.") else k, v) for k, v in state.items())
+    model.load_state_dict(clean)
+    return model
+
+
+def psnr(pred, target, data_range=None):
+    """Host float: 10*log10(range^2 / MSE(pred, target)) for fp32 NCHW device tensors."""
+    mse = float(F.mse_loss(pred.detach(), target.detach()))
+    if data_range is None:
+        data_range = float(target.max() - target.min())
+    return 10.0 * math.log10(data_range ** 2 / mse) if mse > 0 else float("inf")
+
+
+def to_uint8_image(img):
+    """[3,H,W] float in [0,1] -> [H,W,3] uint8 numpy (eval_GAN.py:55-56; values are clipped first, the reference's bare
+    ``astype(np.uint8)`` wraps out-of-range values)."""
+    return (img.detach().clamp(0.0, 1.0) * 255.0).round().to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+
+
+def evaluate_generator(gen, pairs, tile=None, out_dir=None, data_range=None, dtype=torch.float16, to_unit=None):
+    """eval_GAN.py:21-69 for an iterable of (LR [1,3,h,w], HR [1,3,H,W], name) on the device.
+
+    Returns {'avg_psnr': ..., 'psnr': {name: value}}.  ``out_dir`` (optional) receives <out_dir>/images/<name>.png like
+    save_image (utils/common.py:20-33); ``to_unit`` maps the network's output range to [0,1] for the PNG (default:
+    identity, as in the reference)."""
+    per = OrderedDict()
+    for lr_image, hr_image, name in pairs:
+        if isinstance(name, (list, tuple)):
+            name = name[0]                                  # DataLoader collation of a batch of one (eval_GAN.py:40)
+        resolved = infer.super_resolve(gen, lr_image, tile=tile, dtype=dtype)
+        per[name] = psnr(resolved, hr_image, data_range)
+        if out_dir is not None:
+            from PIL import Image
+            img_dir = os.path.join(out_dir, "images")
+            os.makedirs(img_dir, exist_ok=True)
+            img = resolved[0] if to_unit is None else to_unit(resolved[0])
+            Image.fromarray(to_uint8_image(img)).save(os.path.join(img_dir, f"{name}.png"))
+    return {"avg_psnr": sum(per.values()) / max(len(per), 1), "psnr": per}

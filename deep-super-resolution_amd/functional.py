@@ -84,6 +84,19 @@ def clear_pack_cache():
     _pack_cache.clear()
 
 
+def check_prelu_slopes(module):
+    """Raise if a one-parameter nn.PReLU of `module` that feeds a fused conv+PReLU launch (generator.py:48,34: the head
+    and the PixelShuffle blocks) holds a slope <= 0: those launches keep only the activation OUTPUT, from which the
+    backward can tell the branch for a positive slope only (see ConvAct).  One host sync; call it between steps."""
+    import torch.nn as nn
+    bad = [(name, float(m.weight.detach().min())) for name, m in module.named_modules()
+           if isinstance(m, nn.PReLU) and not float(m.weight.detach().min()) > 0.0]
+    if bad:
+        raise RuntimeError("PReLU slope(s) not positive: " + ", ".join(f"{n}.weight={v:g}" for n, v in bad) +
+                           " -- conv+PReLU launches that store only the activation output cannot back-propagate "
+                           "through them (their gradients are NaN by construction)")
+
+
 def packed_weights(weight, desc, dtype):
     """16-bit [T][Cout_p][Cin_p] (forward) and [T][Cin_p][Cout_p] (dgrad) images of an OIHW fp32 weight."""
     key = (id(weight), dtype, tuple(weight.shape))
@@ -238,11 +251,18 @@ class ConvAct(torch.autograd.Function):
     generator.py:47-48 (9x9 + PReLU), :30-39 (3x3 64->256 + PixelShuffle + PReLU: a one-parameter
     PReLU commutes with the shuffle permutation), discriminator.py:25-27 (3x3 + LeakyReLU),
     utils/GAN.py:19-57 (VGG 3x3 + ReLU), plain convs (act none).
-    Backward derives act' from the stored OUTPUT, which needs a positive PReLU/LeakyReLU slope."""
+    Backward derives act' from the stored OUTPUT (the pre-activation is never written to HBM), which identifies the
+    branch only for a POSITIVE slope.  A LeakyReLU slope is a host constant and is checked here; a learned PReLU slope
+    lives on the device: if it has crossed zero the backward kernel turns every gradient of the launch into NaN (never
+    a silently wrong number) and ``check_prelu_slopes(module)`` names the parameter.  ConvBNAct has no such
+    restriction (it re-derives the sign from the saved conv output)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, prelu, cfg):
         _need_gpu(x)
+        if cfg.get("act", ACT_NONE) == ACT_LEAKY and not float(cfg.get("slope", 0.0)) > 0.0:
+            raise ValueError(f"ConvAct: LeakyReLU slope {cfg.get('slope', 0.0)} must be > 0 (the activation gradient is "
+                             "derived from the stored output)")
         x = x.contiguous()
         cout, cin, kh, kw = weight.shape
         desc = make_desc(x, cout, kh, kw, cfg["stride"], cfg["pad"], cfg.get("pad_mode", PAD_ZERO), cin)
@@ -464,15 +484,31 @@ class ConvOutNCHW(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- losses
+def axpby(x, y=None, a=1.0, b=1.0, g=None):
+    """(a * x + b * y) * g on fp32 tensors (y optional, g an optional 0-dim / 1-element device tensor): dsr_pw_axpby_f32."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    if y is not None:
+        y = y.contiguous()
+        assert y.shape == x.shape and y.dtype == torch.float32
+    if g is not None:
+        g = g.contiguous().float()
+    check(_lib.lib().dsr_pw_axpby_f32(_ptr(x), _ptr(y), float(a), float(b), _ptr(g), _ptr(out), x.numel(), _stream()))
+    return out
+
+
 class DiffLoss(torch.autograd.Function):
     """mean |a-b| (mode 0, BASELINE config 2) or mean (a-b)^2 (mode 1, nn.MSELoss: DIP.py:26,65;
-    utils/GAN.py:74,90) over fp32 tensors; gradient w.r.t. the first argument only."""
+    utils/GAN.py:74,90) over fp32 tensors.  Both arguments are differentiable (nn.MSELoss / nn.L1Loss are):
+    d/d target = - d/d pred."""
 
     @staticmethod
     def forward(ctx, pred, target, mode):
         _need_gpu(pred)
         pred = pred.contiguous().float()
         target = target.contiguous().float()
+        if pred.shape != target.shape:
+            raise RuntimeError(f"loss operands differ in shape: {tuple(pred.shape)} vs {tuple(target.shape)}")
         n = pred.numel()
         blocks = max(1, min(1024, (n + 1023) // 1024))
         part = torch.empty(blocks, dtype=torch.float32, device=pred.device)
@@ -487,7 +523,9 @@ class DiffLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None, None
+        gp = axpby(grad, None, 1.0, 0.0, g) if ctx.needs_input_grad[0] else None
+        gt = axpby(grad, None, -1.0, 0.0, g) if ctx.needs_input_grad[1] else None
+        return gp, gt, None
 
 
 def l1_loss(pred, target):
@@ -514,11 +552,44 @@ class BCEConst(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None
+        return axpby(grad, None, 1.0, 0.0, g), None
 
 
 def bce_const(p, target):
     return BCEConst.apply(p, target)
+
+
+class AddScalars(torch.autograd.Function):
+    """a + b for two scalar losses (utils/GAN.py:105 BCE(real,1) + BCE(fake,0); :122 content + adversarial)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return axpby(a.reshape(1), b.reshape(1), 1.0, 1.0).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add_losses(a, b):
+    return AddScalars.apply(a, b)
+
+
+class ScaleLoss(torch.autograd.Function):
+    """s * loss for a host constant s (the static loss scale of the fp16 DIP path)."""
+
+    @staticmethod
+    def forward(ctx, loss, s):
+        ctx.s = float(s)
+        return axpby(loss.reshape(1), None, ctx.s, 0.0).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return axpby(g.reshape(1), None, ctx.s, 0.0).reshape(()), None
+
+
+def scale_loss(loss, s):
+    return loss if s == 1.0 else ScaleLoss.apply(loss, s)
 
 
 # ----------------------------------------------------------------------------- discriminator dense head

@@ -75,7 +75,7 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
 
     def d_half():
         real_d, fake_d = disc.forward_pair(hr_patches, fake_det, fa=real_feat)   # :44, :47 (BN statistics per batch, as there)
-        loss_d = F.bce_const(real_d, 1.0) + F.bce_const(fake_d, 0.0)  # :48, utils/GAN.py:101-105
+        loss_d = F.add_losses(F.bce_const(real_d, 1.0), F.bce_const(fake_d, 0.0))  # :48, utils/GAN.py:101-105
         opt_d.zero_grad()                                        # :51 (gan_D.zero_grad())
         loss_d.backward()                                        # :52
         _mark("D: backward done", torch.cuda.current_stream())
@@ -112,7 +112,7 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
         main.wait_stream(side)                                   # D half done before anything later on `main`
         loss_d.record_stream(main)
         adv.record_stream(main)
-    loss_g = content.detach() + adv                              # :59 value (unweighted sum, utils/GAN.py:122)
+    loss_g = F.add_losses(content.detach(), adv)                  # :59 value (unweighted sum, utils/GAN.py:122)
     return loss_d, loss_g, fake_det
 
 
@@ -171,6 +171,6 @@ class DipRunner:
         out_hr = self.net(self.net_input)                        # :60
         out_lr = self.down(out_hr)                               # :62
         loss = F.mse_loss(out_lr, self.lr_image)                 # :65
-        (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()   # :68
+        F.scale_loss(loss, self.loss_scale).backward()           # :68
         self.opt.step()
         return loss.detach(), out_hr.detach()

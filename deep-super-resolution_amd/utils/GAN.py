@@ -182,7 +182,7 @@ def get_adversarial_loss(fake_output, bce_loss=None):
 
 
 def get_loss_D(real_output, fake_output, bce_loss=None):
-    return F.bce_const(real_output, 1.0) + F.bce_const(fake_output, 0.0)
+    return F.add_losses(F.bce_const(real_output, 1.0), F.bce_const(fake_output, 0.0))
 
 
 class PerceptualLoss(nn.Module):
@@ -199,4 +199,4 @@ class PerceptualLoss(nn.Module):
     def forward(self, fake_output_G, HR_images, fake_output_D, bce_loss=None):
         content_loss = self.content(fake_output_G, HR_images)
         adversarial_loss_ = self.adversarial(fake_output_D, bce_loss)
-        return content_loss + adversarial_loss_                   # unweighted sum (:122)
+        return F.add_losses(content_loss, adversarial_loss_)      # unweighted sum (:122)

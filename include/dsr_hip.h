@@ -151,6 +151,10 @@ int dsr_pw_act_bwd_nchw(int dtype, const float* dout, const float* out, void* dy
                         int act, dsr_stream_t s);
 int dsr_pw_colsum(int dtype, const void* x, size_t P, int Cp, int blocks, int rpb, float* partial, dsr_stream_t s);
 int dsr_pw_add(int dtype, const void* a, const void* b, void* out, size_t nvec, dsr_stream_t s);
+/* out[i] = (a * x[i] + b * y[i]) * g[0] over n fp32 elements; y nullable (-> 0), g nullable device scalar (-> 1).
+ * The scalar arithmetic of the step recipes (utils/GAN.py:105,122 loss sums; loss-gradient scaling). */
+int dsr_pw_axpby_f32(const float* x, const float* y, float a, float b, const float* g, float* out, size_t n,
+                     dsr_stream_t s);
 int dsr_pw_diff_loss(const float* pred, const float* tgt, float* grad, size_t n, int mode, float* partial, int blocks,
                      dsr_stream_t s);
 int dsr_pw_bce_const(const float* p, int n, float target, float* loss, float* grad, int accumulate, dsr_stream_t s);

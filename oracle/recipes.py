@@ -37,14 +37,20 @@ class GanState:
         self.vgg_resize, self.vgg_crop = vgg_resize, vgg_crop
 
 
-def gan_step(st, lr_patches, hr_patches):
-    """One do_epoch (train_GAN.py:38-71).  Returns (loss_D, loss_G, fake) as floats/tensor."""
+def gan_step(st, lr_patches, hr_patches, capture=None):
+    """One do_epoch (train_GAN.py:38-71).  Returns (loss_D, loss_G, fake) as floats/tensor.
+
+    ``capture`` (a dict, tests only) receives clones of the gradients the two optimiser steps consume:
+    ``capture["d_grads"]`` after :52 (before the dead BCE gradient of :63 is accumulated on top of them) and
+    ``capture["g_grads"]`` after :63, keyed like the state_dicts."""
     real_d = gan.discriminator_forward(st.d, hr_patches, True)              # :44
     fake = gan.generator_forward(st.g, lr_patches, True).detach()           # :46
     fake_d = gan.discriminator_forward(st.d, fake, True)                    # :47
     loss_d = losses.loss_d(real_d, fake_d)                                  # :48
     zero_grad(st.d_params)                                                  # :51
     loss_d.backward()                                                       # :52
+    if capture is not None:
+        capture["d_grads"] = {k: st.d[k].grad.detach().clone() for k in gan.trainable(st.d)}
     st.opt_d.step()                                                         # :53
 
     fake = gan.generator_forward(st.g, lr_patches, True)                    # :56
@@ -53,6 +59,9 @@ def gan_step(st, lr_patches, hr_patches):
     loss_g = content + losses.adversarial(fake_d)                           # :59, utils/GAN.py:122
     zero_grad(st.g_params)                                                  # :62
     loss_g.backward()                                                       # :63
+    if capture is not None:
+        capture["g_grads"] = {k: st.g[k].grad.detach().clone() for k in gan.trainable(st.g)}
+        capture["content"] = float(content.detach())
     st.opt_g.step()                                                         # :64
     return float(loss_d.detach()), float(loss_g.detach()), fake.detach()
 

@@ -42,7 +42,7 @@ def test_ctypes_signatures_match_header(so):
     for name, (_, args) in L.SIGNATURES.items():
         assert len(args) == decl[name], (name, len(args), decl[name])
     L.lib()
-    assert L.lib().dsr_abi_version() == 1
+    assert L.lib().dsr_abi_version() == L.ABI_VERSION == 2
 
 
 def test_host_side_descriptor_checks(so):
@@ -62,6 +62,103 @@ def test_host_side_descriptor_checks(so):
     assert lib.dsr_conv_out_size(ctypes.byref(refl), ctypes.byref(oh), ctypes.byref(ow)) < 0
     with pytest.raises(RuntimeError):
         L.check(-1)
+
+
+def test_bad_arguments_return_codes_not_crashes(so):
+    """Round-1 bring-up crashes, restated as contract tests.  Every entry point validates on the host and
+    returns a negative code BEFORE anything is launched: a null device pointer would otherwise become a GPU memory fault
+    (the runtime aborts the process: the 07:11 abort in test_conv_act_fwd_bwd came from a partial-sum buffer that was too
+    small for the compaction pass behind it), a null HOST table a segfault.  None of these calls needs a GPU."""
+    L = importlib.import_module(PKG + "._lib")
+    lib = L.lib()
+    N = None
+    st = None
+    one = ctypes.c_void_p(16)            # a non-null "pointer" that is never dereferenced: validation fails first
+    d = L.ConvDesc(L.BF16, 2, 16, 16, 64, 64, 3, 3, 1, 1, 0)
+    ep = L.Epilogue(0, 0.0, N, N, N, 0, N, N, N, N)
+    calls = [
+        lambda: lib.dsr_conv_out_size(N, N, N),
+        lambda: lib.dsr_conv_out_size(ctypes.byref(d), N, N),
+        lambda: lib.dsr_conv_fwd(ctypes.byref(d), N, N, ctypes.byref(ep), N, st),
+        lambda: lib.dsr_conv_fwd(N, one, one, ctypes.byref(ep), one, st),
+        lambda: lib.dsr_conv_dgrad(ctypes.byref(d), N, N, N, N, 0, st),
+        lambda: lib.dsr_conv_wgrad(ctypes.byref(d), N, N, N, N, 0, st),
+        lambda: lib.dsr_conv_pack_weight(ctypes.byref(d), N, N, N, st),
+        lambda: lib.dsr_conv_pack_weight_multi(0, 3, N, N, N, N, N, N, st),
+        lambda: lib.dsr_conv_first_bwd(ctypes.byref(d), N, N, N, 1, 0.2, N, N, N, 0, st),
+        lambda: lib.dsr_pw_nchw_to_nhwc(0, N, N, 1, 3, 4, 4, 8, st),
+        lambda: lib.dsr_pw_nhwc_to_nchw(0, one, one, 1, 3, 4, 4, 7, st),          # Cp % 8
+        lambda: lib.dsr_pw_sum_rows(N, 4, 8, 0, 8, 1.0, N, 0, 1, st),
+        lambda: lib.dsr_pw_bn_finalize(N, 4, 64, 64, 64, 16.0, N, N, N, N, N, 0.1, 1e-5, 1, N, N, N, N, st),
+        lambda: lib.dsr_pw_bn_eval_affine(N, N, N, N, 1e-5, 64, 64, N, N, N, N, st),
+        lambda: lib.dsr_pw_reduce_blocks(1024, N),
+        lambda: lib.dsr_pw_channel_stats(0, N, 64, 64, 1, 64, N, st),
+        lambda: lib.dsr_pw_bn_act_fwd(0, N, N, N, N, N, 64, 64, 0, 0.0, N, st),
+        lambda: lib.dsr_pw_bn_act_fwd(0, one, one, one, N, one, 64, 4096, 0, 0.0, N, st),   # Cp > 2048: no pixel row per block
+        lambda: lib.dsr_pw_bn_act_fwd(2, one, one, one, N, one, 64, 64, 0, 0.0, N, st),     # dtype
+        lambda: lib.dsr_pw_bn_act_fwd(0, one, one, one, N, one, 64, 64, L.ACT_PRELU, 0.0, N, st),   # PReLU without its weight
+        lambda: lib.dsr_pw_bn_act_bwd_reduce(0, N, N, N, N, N, N, 64, 64, 1, 64, 0, 0.0, N, N, st),
+        lambda: lib.dsr_pw_bn_bwd_finalize(N, 1, 64, 64, 64.0, N, N, N, N, N, st),
+        lambda: lib.dsr_pw_bn_act_bwd_apply(0, N, N, N, N, N, N, N, N, N, 64, 64, 0, 0.0, N, 1, st),
+        lambda: lib.dsr_pw_act_bwd(0, N, N, N, 1, 4, 4, 64, 64, 0, 1, 0.2, N, 1, 64, N, st),
+        lambda: lib.dsr_pw_act_bwd(0, one, one, one, 1, 4, 4, 64, 64, 0, L.ACT_LEAKY, -0.1, N, 1, 64, N, st),   # slope <= 0
+        lambda: lib.dsr_pw_act_bwd(0, one, one, one, 1, 4, 4, 64, 64, 0, L.ACT_LEAKY, 0.0, N, 1, 64, N, st),
+        lambda: lib.dsr_pw_act_bwd(0, one, one, one, 1, 4, 4, 64, 64, 0, L.ACT_PRELU, 0.0, N, 1, 64, N, st),    # PReLU, no weight
+        lambda: lib.dsr_pw_act_bwd_nchw(0, N, N, N, 1, 3, 4, 4, 8, 4, st),
+        lambda: lib.dsr_pw_colsum(0, N, 64, 64, 1, 64, N, st),
+        lambda: lib.dsr_pw_add(0, N, N, N, 8, st),
+        lambda: lib.dsr_pw_axpby_f32(N, N, 1.0, 1.0, N, N, 4, st),
+        lambda: lib.dsr_pw_diff_loss(N, N, N, 16, 0, N, 1, st),
+        lambda: lib.dsr_pw_diff_loss(one, one, one, 16, 7, one, 1, st),           # mode
+        lambda: lib.dsr_pw_bce_const(N, 4, 1.0, N, N, 0, st),
+        lambda: lib.dsr_pw_adam(N, N, N, N, 16, 1e-3, 0.9, 0.999, 1e-8, N, 1.0, N, st),
+        lambda: lib.dsr_pw_adam_multi(2, N, N, N, N, N, 1e-3, 0.9, 0.999, 1e-8, N, 1.0, st),
+        lambda: lib.dsr_pw_incr(N, st),
+        lambda: lib.dsr_cast16(0, N, N, 16, st),
+        lambda: lib.dsr_flatten(0, N, N, 2, 4, 8, 8, 0, 0, st),
+        lambda: lib.dsr_linear_fwd(0, N, N, N, 1, 0.2, N, 4, 64, 8, N, 0, st),
+        lambda: lib.dsr_linear_dgrad(0, N, N, N, 4, 8, 64, st),
+        lambda: lib.dsr_linear_wgrad(0, N, N, N, 32, 8, 64, st),
+        lambda: lib.dsr_linear_wgrad_gathered(0, N, N, N, 32, 8, 64, 2, 0.5, st),
+        lambda: lib.dsr_dense2_fwd(N, N, N, 4, 8, N, st),
+        lambda: lib.dsr_dense2_bwd(0, N, N, N, N, 4, 8, 32, 0.2, N, N, N, N, N, st),
+        lambda: lib.dsr_maxpool2_fwd(0, N, N, 1, 4, 4, 8, st),
+        lambda: lib.dsr_maxpool2_bwd(0, N, N, N, 1, 4, 4, 8, st),
+        lambda: lib.dsr_avgpool2_fwd(0, N, N, 1, 4, 4, 8, st),
+        lambda: lib.dsr_avgpool2_bwd(0, N, N, 1, 4, 4, 8, st),
+        lambda: lib.dsr_nearest2x_fwd(0, N, N, 1, 4, 4, 8, st),
+        lambda: lib.dsr_nearest2x_bwd(0, N, N, 1, 4, 4, 8, st),
+        lambda: lib.dsr_bilinear2x_fwd(0, N, N, 1, 4, 4, 8, st),
+        lambda: lib.dsr_bilinear2x_bwd(0, N, N, 1, 4, 4, 8, st),
+        # mean3 / std3 are HOST arrays that the launcher reads: null used to be a host segfault
+        lambda: lib.dsr_resize_norm_fwd(0, one, one, 1, 3, 8, 8, 4, 4, one, one, one, one, one, one, 2, N, N, st),
+        lambda: lib.dsr_resize_norm_bwd(0, one, one, 1, 3, 8, 8, 4, 4, one, one, one, one, one, one, 2, N, st),
+        lambda: lib.dsr_box_copy(N, N, 1, 2, 2, 4, 4, 4, 8, 0, 0, 0, 4, 4, 8, 0, 0, 0, st),
+        lambda: lib.dsr_downsample_fwd(N, N, N, 3, 8, 8, 4, 2, 1, st),
+        lambda: lib.dsr_downsample_bwd(N, N, N, 3, 8, 8, 4, 2, 1, st),
+    ]
+    for i, call in enumerate(calls):
+        rc = call()
+        assert rc < 0, f"call #{i} returned {rc}"
+        assert lib.dsr_last_error(), i
+    # size queries on a bad descriptor answer 0 instead of dereferencing it
+    assert lib.dsr_conv_packed_elems(N, 0) == 0 and lib.dsr_conv_dgrad_workspace(N) == 0
+    assert lib.dsr_conv_wgrad_workspace(N) == 0 and lib.dsr_conv_first_bwd_workspace(N) == 0
+    assert lib.dsr_conv_stats_rows(N) < 0 and lib.dsr_conv_fwd_affine_supported(N) == 0
+    assert lib.dsr_conv_kernel_name(N, 0, N) == b"invalid"
+
+
+def test_entry_point_without_return_does_not_compile(tmp_path):
+    """The 06:58 round-1 segfault (functional.py:286, inside dsr_pw_bn_eval_affine): that entry point had lost its
+    `return` statement -- undefined behaviour, hipcc -O3 emits no `ret` and the host runs off the function's end.  The
+    build now carries -Werror=return-type; this checks the flag is there and does what it is there for."""
+    b = importlib.import_module(PKG + "._build")
+    assert "-Werror=return-type" in b.FLAGS
+    src = tmp_path / "noret.hip"
+    src.write_text('extern "C" int f(int x) { if (x) return 1; }\n')
+    import subprocess
+    r = subprocess.run(["hipcc"] + b.FLAGS + ["-c", str(src), "-o", str(tmp_path / "noret.o")], capture_output=True, text=True)
+    assert r.returncode != 0 and "return" in r.stderr
 
 
 def test_product_never_imports_oracle():
