@@ -98,6 +98,39 @@ SIGNATURES = {
 
 _lib = None
 
+# bench.py's roofline leg: a list here makes every launching entry point record (name, start_event, end_event) on the
+# stream it launches on (torch's current stream), so that the GPU-busy share of a step can be told from launch gaps.
+LAUNCH_LOG = None
+_NO_LAUNCH = ("dsr_last_error", "dsr_abi_version", "dsr_conv_kernel_name", "dsr_conv_fwd_affine_supported",
+              "dsr_conv_first_bwd_supported", "dsr_conv_first_bwd_workspace", "dsr_conv_out_size", "dsr_conv_stats_rows",
+              "dsr_conv_packed_elems", "dsr_conv_dgrad_workspace", "dsr_conv_wgrad_workspace", "dsr_pw_scratch_rows",
+              "dsr_pw_reduce_blocks", "dsr_linear_fwd_workspace")
+
+
+class _Lib:
+    """The loaded shared object; attribute access returns the bound C function (optionally timed, see LAUNCH_LOG)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        for name in SIGNATURES:
+            fn = getattr(handle, name)
+            setattr(self, name, fn if name in _NO_LAUNCH else self._timed(name, fn))
+
+    @staticmethod
+    def _timed(name, fn):
+        def call(*args):
+            log = LAUNCH_LOG
+            if log is None:
+                return fn(*args)
+            import torch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            log.append((name, e0, e1))
+            return rc
+        return call
+
 
 def lib():
     """The loaded library; raises if it was not built (run __graft_entry__.build())."""
@@ -117,7 +150,7 @@ def lib():
             # kernels then read sizes as pointers -- refuse to run instead (round-1 bring-up abort)
             raise RuntimeError(f"{SO_PATH}: C-ABI version {got}, this binding expects {ABI_VERSION}; rebuild with "
                                "`python -c 'import __graft_entry__ as g; g.build()'`")
-        _lib = h
+        _lib = _Lib(h)
     return _lib
 
 

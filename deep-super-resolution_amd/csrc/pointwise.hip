@@ -571,6 +571,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const unsigned short* __re
         g[k] = d[k] * act_grad_from_out(act, o[k], slope) + poison;
         sb[k] += g[k];
         if (act == DSR_ACT_PRELU && o[k] < 0.f) sp[k] += d[k] * (o[k] / slope);
+        sp[k] += poison;
       }
       *reinterpret_cast<U4*>(dy + p * CyP + ch * 8) = pack8<DT>(g);
     }

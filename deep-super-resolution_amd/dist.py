@@ -57,6 +57,11 @@ class GradSync:
         self._early = set()
         self._hooks = []
         self._plan_key, self._buckets = None, []
+        # measurement aid (bench.py --gpus N): with `timing` set, wait() brackets the stream-side wait for the
+        # collectives with events; pop_wait_ms() returns the accumulated milliseconds the compute stream spent parked
+        # behind communication (exposed, i.e. NOT overlapped, collective time) since the last call
+        self.timing = False
+        self._wait_events = []
 
     def attach(self, factor_gather=True):
         """``factor_gather``: 2-D parameters of at least ``big_bytes`` (the dense head's K x 1024 matrix) are marked
@@ -140,6 +145,10 @@ class GradSync:
         """Block the current stream until the averages have landed; afterwards every small parameter's .grad is a view
         of its bucket (valid until the next launch(), like DDP's gradient_as_bucket_view)."""
         world = dist.get_world_size() if self._pending else 1
+        timed = self.timing and self._pending and self._pending[0][2].is_cuda
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for kind, work, buf, items, divide in self._pending:
             work.wait()
             if divide:
@@ -147,8 +156,19 @@ class GradSync:
             if kind == "bucket":
                 for p, v in items:
                     p.grad = v
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._wait_events.append((e0, e1))
         self._pending = []
         self._early = set()
+
+    def pop_wait_ms(self):
+        """Milliseconds the compute stream waited for collectives in the wait() calls since the last pop (needs a device
+        sync by the caller first).  0.0 when nothing was timed."""
+        ms = sum(a.elapsed_time(b) for a, b in self._wait_events)
+        self._wait_events = []
+        return ms
 
     def __call__(self):
         self.launch()

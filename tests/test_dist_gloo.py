@@ -69,6 +69,59 @@ def test_grad_sync_world2():
     assert sorted(res) == [(0, True), (1, True)]
 
 
+def _factor_worker(rank, world, port, q):
+    """The dense head's data-parallel gradient (functional.DenseHead.backward): instead of all-reducing dW1 = dy^T x
+    (2.1 GB at 512x512), every rank all-gathers the two rank-local FACTORS and forms (1/R) sum_r dy_r^T x_r itself.
+    Here the exchange runs over gloo on CPU-resident factors (the same functional._gather_factors the GPU path calls;
+    the MFMA product dsr_linear_wgrad_gathered is replaced by a plain matmul) and must equal the all-reduced mean."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    F = importlib.import_module(PKG + ".functional")
+    D = importlib.import_module(PKG + ".dist")
+    o, k, bp, b = 24, 200, 32, 5
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(b, k, generator=g)            # this rank's flattened features [batch, K]
+    dy = torch.randn(b, o, generator=g)           # this rank's dense1 output gradient [batch, O]
+    xt, dyt = torch.zeros(k, bp), torch.zeros(o, bp)        # batch-minor, zero padded: the layout DenseHead exchanges
+    xt[:, :b], dyt[:, :b] = x.t(), dy.t()
+    xt_all, dyt_all, works = F._gather_factors(xt, dyt, world)
+    for wk in works:
+        wk.wait()
+    ok = tuple(xt_all.shape) == (world, k, bp) and tuple(dyt_all.shape) == (world, o, bp)
+    ok = ok and torch.equal(xt_all[rank], xt) and torch.equal(dyt_all[rank], dyt)
+    from_factors = sum(dyt_all[r] @ xt_all[r].t() for r in range(world)) / world
+    # the plain alternative (DSR_DP_FACTOR_GATHER=0): local gradient, averaged by GradSync's all-reduce
+    w1 = torch.nn.Parameter(torch.zeros(o, k))
+    w1.grad = dy.t() @ x
+    D.GradSync([w1], big_bytes=1)()               # big path: in-place all-reduce
+    ok = ok and torch.allclose(from_factors, w1.grad, rtol=1e-5, atol=1e-5)
+    # a parameter marked as produced globally (attach(factor_gather=True) on the dense head) is left alone by GradSync
+    w2 = torch.nn.Parameter(torch.zeros(o, k))
+    w2._dsr_dense_head = True
+    sync = D.GradSync([w2], big_bytes=1).attach()
+    ok = ok and getattr(w2, "_dsr_grad_global", False) and F.dp_world_for(w2) == world
+    w2.grad = torch.full((o, k), float(rank + 1))
+    sync()
+    ok = ok and torch.equal(w2.grad, torch.full((o, k), float(rank + 1)))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_dense_head_factor_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30100 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_factor_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
 def test_grad_sync_noop_single_process():
     sys.path.insert(0, ROOT)
     D = importlib.import_module(PKG + ".dist")

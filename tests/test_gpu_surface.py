@@ -1,0 +1,287 @@
+"""GPU: the rows next to the hot path -- activation-slope guards, differentiable loss targets, the LBFGS branch of
+utils/DIP.optimize over the HIP closure, a caller-supplied VGG state_dict, reference-format checkpoints through the
+mirror with the golden eval output, and the evaluation loop (PSNR, tiles, PNG)."""
+import importlib
+import math
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from oracle import dip, downsampler, filler, gan, losses, recipes, vgg
+
+pytestmark = pytest.mark.gpu
+PKG = "deep-super-resolution_amd"
+
+
+def P(sub):
+    return importlib.import_module(PKG + "." + sub)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    P("_lib").lib()
+    return torch.device("cuda:0")
+
+
+def bfr(t):
+    return t.to(torch.bfloat16).float()
+
+
+def to_nhwc(x, cp=None):
+    n, c, h, w = x.shape
+    cp = cp or (c + 7) // 8 * 8
+    out = torch.zeros(n, h, w, cp, dtype=torch.bfloat16)
+    out[..., :c] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    return out
+
+
+def from_nhwc(y, c):
+    return y[..., :c].float().permute(0, 3, 1, 2).contiguous()
+
+
+def rel_err(got, ref):
+    got, ref = got.double(), ref.double()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-20))
+
+
+# ----------------------------------------------------------------------------- PReLU slope sign
+@pytest.mark.parametrize("slope", [0.25, -0.1, 0.0])
+def test_conv_prelu_any_slope(dev, slope):
+    """conv + one-parameter PReLU (generator.py:47-48).  Forward is exact for every slope.  Backward of the fused launch
+    keeps only the activation OUTPUT, so it is defined for slope > 0 (checked against torch); for slope <= 0 it must be
+    LOUD -- all-NaN gradients and functional.check_prelu_slopes() raising -- never a finite wrong number.  The
+    conv+BN+PReLU launches re-derive the sign from the saved conv output and are exact for every slope."""
+    F = P("functional")
+    n, cin, cout, h, w = 2, 16, 32, 10, 12
+    x = bfr(filler.tensor("ps:x", (n, cin, h, w)))
+    wt = bfr(filler.tensor("ps:w", (cout, cin, 3, 3), float(np.sqrt(3.0 / (cin * 9)))))
+    b = filler.tensor("ps:b", (cout,), 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ar = torch.tensor([slope], requires_grad=True)
+    yr = TF.prelu(TF.conv2d(xr, wr, br, padding=1), ar)
+    probe = bfr(filler.tensor("ps:p", tuple(yr.shape)))
+    (yr * probe).sum().backward()
+    xg = to_nhwc(x).to(dev).requires_grad_(True)
+    wg, bg = wt.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    prelu = torch.nn.PReLU().to(dev)
+    with torch.no_grad():
+        prelu.weight.fill_(slope)
+    yg = F.ConvAct.apply(xg, wg, bg, prelu.weight, dict(stride=1, pad=1, act=F.ACT_PRELU))
+    assert rel_err(from_nhwc(yg.detach().cpu(), cout), yr.detach()) < 1.2e-2
+    yg.backward(to_nhwc(probe).to(dev))
+    torch.cuda.synchronize()
+    if slope > 0:
+        F.check_prelu_slopes(prelu)
+        assert rel_err(from_nhwc(xg.grad.cpu(), cin), xr.grad) < 2.5e-2
+        assert rel_err(wg.grad.cpu(), wr.grad) < 2.5e-2
+        assert abs(float(prelu.weight.grad) - float(ar.grad)) < 2.5e-2 * max(1.0, abs(float(ar.grad)))
+    else:
+        assert torch.isnan(xg.grad).all() and torch.isnan(wg.grad).all() and torch.isnan(prelu.weight.grad).all()
+        with pytest.raises(RuntimeError, match="PReLU slope"):
+            F.check_prelu_slopes(prelu)
+    # conv + BatchNorm + PReLU (generator.py:15-18): exact for every slope
+    gamma, beta = filler.tensor("ps:g", (cout,), 0.2, 1.0), filler.tensor("ps:be", (cout,), 0.1)
+    xr2, wr2 = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    gr, ber, ar2 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True), torch.tensor([slope], requires_grad=True)
+    zr = TF.batch_norm(TF.conv2d(xr2, wr2, b, padding=1), None, None, gr, ber, training=True, eps=1e-5)
+    yr2 = TF.prelu(zr, ar2)
+    (yr2 * probe).sum().backward()
+    xg2 = to_nhwc(x).to(dev).requires_grad_(True)
+    wg2 = wt.to(dev).requires_grad_(True)
+    gg, beg = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+    ag2 = torch.tensor([slope], device=dev, requires_grad=True)
+    rm, rv, nbt = torch.zeros(cout, device=dev), torch.ones(cout, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
+    yg2 = F.ConvBNAct.apply(xg2, wg2, b.to(dev), gg, beg, rm, rv, nbt, ag2, None,
+                            dict(stride=1, pad=1, act=F.ACT_PRELU, train=True))
+    yg2.backward(to_nhwc(probe).to(dev))
+    assert rel_err(from_nhwc(yg2.detach().cpu(), cout), yr2.detach()) < 1.5e-2
+    assert rel_err(from_nhwc(xg2.grad.cpu(), cin), xr2.grad) < 3e-2
+    assert rel_err(wg2.grad.cpu(), wr2.grad) < 3e-2
+    assert rel_err(gg.grad.cpu(), gr.grad) < 2e-2 and rel_err(beg.grad.cpu(), ber.grad) < 2e-2
+    assert abs(float(ag2.grad) - float(ar2.grad)) < 2.5e-2 * max(1.0, abs(float(ar2.grad)))
+
+
+def test_leaky_slope_must_be_positive(dev):
+    F = P("functional")
+    x = to_nhwc(filler.tensor("ls:x", (1, 8, 6, 6))).to(dev)
+    w = filler.tensor("ls:w", (8, 8, 3, 3)).to(dev)
+    with pytest.raises(ValueError, match="slope"):
+        F.ConvAct.apply(x, w, None, None, dict(stride=1, pad=1, act=F.ACT_LEAKY, slope=-0.2))
+
+
+# ----------------------------------------------------------------------------- losses
+@pytest.mark.parametrize("mode", ["mse", "l1"])
+def test_loss_differentiates_both_arguments(dev, mode):
+    """nn.MSELoss / nn.L1Loss differentiate prediction AND target (Vgg19Loss.forward with an image2 that requires grad,
+    utils/GAN.py:84-90); the incoming scalar gradient is applied by the HIP axpby kernel."""
+    F = P("functional")
+    a, b = filler.tensor("dl:a", (2, 3, 9, 11)), filler.tensor("dl:b", (2, 3, 9, 11))
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = (TF.mse_loss if mode == "mse" else TF.l1_loss)(ar, br)
+    (ref * 3.0).backward()
+    ag, bg = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    loss = (F.mse_loss if mode == "mse" else F.l1_loss)(ag, bg)
+    F.scale_loss(loss, 3.0).backward()
+    assert abs(loss.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
+    assert torch.allclose(ag.grad.cpu(), ar.grad, rtol=1e-5, atol=1e-8)
+    assert torch.allclose(bg.grad.cpu(), br.grad, rtol=1e-5, atol=1e-8)
+    s = F.add_losses(loss.detach(), loss.detach())
+    assert abs(s.item() - 2 * ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
+    with pytest.raises(RuntimeError):
+        F.mse_loss(ag, bg[:, :2])
+
+
+# ----------------------------------------------------------------------------- f3: caller-supplied VGG weights
+def test_perceptual_loss_with_supplied_vgg_state_dict(dev):
+    """utils/GAN.py:64-92 with a local torchvision-format ``features`` state_dict: the loss and its gradient are those of
+    the oracle evaluated with THAT dict (no pretrained file exists offline, so the values are synthetic; the code path --
+    key mapping net.0.<i>.*, frozen trunk, 256/224 preprocessing -- is the one a real file takes)."""
+    G = P("utils.GAN")
+    feats = filler.fill_state_dict({k: torch.zeros(v) for k, v in vgg.vgg_shapes().items()}, salt=9)
+    perc = G.PerceptualLoss(vgg_state_dict={k: v.clone() for k, v in feats.items()}).to(dev)
+    assert perc.vgg_loss.pretrained and all(not p.requires_grad for p in perc.parameters())
+    a, b = filler.tensor("pv:a", (1, 3, 96, 96)), filler.tensor("pv:b", (1, 3, 96, 96))
+    ar = a.clone().requires_grad_(True)
+    ref = vgg.vgg_loss(feats, ar, b)
+    ref.backward()
+    ag = a.to(dev).requires_grad_(True)
+    got = perc.content(ag, b.to(dev))
+    got.backward()
+    assert abs(got.item() - ref.item()) < 3e-2 * abs(ref.item()), (got.item(), ref.item())
+    c = float((ag.grad.cpu().double().reshape(-1) @ ar.grad.double().reshape(-1)) /
+              (ag.grad.cpu().double().norm() * ar.grad.double().norm()))
+    assert c > 0.98, c
+    # forward(fake, HR, D(fake)) = content + BCE(D(fake), 1), unweighted (:113-124)
+    pd = torch.tensor([[0.3]], device=dev)
+    tot = perc(ag.detach(), b.to(dev), pd)
+    assert abs(tot.item() - (got.item() - math.log(0.3))) < 1e-4 * max(1.0, abs(tot.item()))
+
+
+# ----------------------------------------------------------------------------- f4: LBFGS branch
+def test_optimize_lbfgs_over_hip_closure(dev):
+    """utils/DIP.py:19-31: 100 Adam steps at lr 1e-3, then one LBFGS.step(max_iter=num_iter) with both tolerances off,
+    driving a HIP closure (skip net -> Lanczos downsampler -> MSE -> backward).  Against the same recipe on the CPU oracle
+    (torch.optim.Adam / torch.optim.LBFGS over the fp32 restatement): the fit must end at the same loss."""
+    M, Dn, U, F = P("models.DIP"), P("utils.downsampler"), P("utils.DIP"), P("functional")
+    kw = dict(skip_n33d=16, skip_n33u=16, skip_n11=4, num_scales=3)
+    cfg = dip.SkipConfig(input_depth=8, **kw)
+    sd = filler.fill_state_dict(gan.template(dip.skip_shapes(cfg)))
+    hr = filler.tensor("in:lb_hr", (1, 3, 32, 32), 0.5, 0.5)
+    lr_img = downsampler.downsampler_forward(hr, 2, "lanczos2", phase=0.5, preserve_size=True)
+    zin = filler.tensor("in:lb_z", (1, 8, 32, 32), 0.05, 0.05)
+    num_iter = 12
+    # --- HIP
+    net = M.get_net(8, "skip", "reflection", upsample_mode="bilinear", **kw)
+    net.load_state_dict(sd)
+    net.to(dev).train()
+    net.compute_dtype = torch.bfloat16          # no loss scale in this loop: bf16's range needs none
+    for m in net.modules():
+        if hasattr(m, "compute_dtype"):
+            m.compute_dtype = torch.bfloat16
+    down = Dn.Downsampler(3, 2, "lanczos2", phase=0.5, preserve_size=True).to(dev)
+    zd, lrd = zin.to(dev), lr_img.to(dev)
+    hist = []
+
+    def closure():
+        loss = F.mse_loss(down(net(zd)), lrd)
+        loss.backward()
+        hist.append(loss.detach())
+        return loss
+
+    U.optimize("LBFGS", U.get_params("net", net, zd), closure, 0.01, num_iter)
+    torch.cuda.synchronize()
+    hip = [float(v) for v in hist]
+    # --- oracle: the reference's own branch text, on the fp32 restatement
+    osd = {k: v.clone() for k, v in sd.items()}
+    params = recipes.leaves(osd)
+    ref = []
+
+    def rclosure():
+        out = dip.skip_forward(osd, zin, cfg, True)
+        loss = losses.mse(downsampler.downsampler_forward(out, 2, "lanczos2", phase=0.5, preserve_size=True), lr_img)
+        loss.backward()
+        ref.append(float(loss.detach()))
+        return loss
+
+    opt = torch.optim.Adam(params, lr=0.001)
+    for _ in range(100):
+        opt.zero_grad()
+        rclosure()
+        opt.step()
+    opt = torch.optim.LBFGS(params, max_iter=num_iter, lr=0.01, tolerance_grad=-1, tolerance_change=-1)
+
+    def rclosure2():
+        opt.zero_grad()
+        return rclosure()
+
+    opt.step(rclosure2)
+    assert len(hip) == len(ref) >= 100 + num_iter               # same number of closure evaluations
+    assert abs(hip[0] - ref[0]) < 0.02 * ref[0]
+    assert abs(hip[99] - ref[99]) < 0.05 * ref[99], (hip[99], ref[99])          # end of the Adam warm-up
+    assert hip[-1] < hip[99] * 1.001 and ref[-1] < ref[99] * 1.001             # LBFGS kept descending on both sides
+    assert abs(hip[-1] - ref[-1]) < 0.08 * ref[-1], (hip[-1], ref[-1])
+
+
+# ----------------------------------------------------------------------------- f2: checkpoints + eval loop
+def test_checkpoint_into_mirror_reproduces_golden_eval(dev, golden, tmp_path):
+    """A reference-format ``.pth`` (plain and DataParallel-prefixed) loaded into the mirror gives the reference's own eval
+    output (tests/golden/generator_g4_r2.npz, computed by the reference class in float64 after two train-mode forwards),
+    and a save -> load round trip on the device is bit-identical."""
+    ev, Gm = P("evaluate"), P("models.GAN.generator")
+    z = golden("generator_g4_r2")
+    sd = filler.fill_state_dict(gan.template(gan.generator_shapes(4, 2)))
+    # the state after the two train-mode forwards of make_golden.py, taken from the ORACLE (pinned to the same fixture)
+    osd = {k: v.clone() for k, v in sd.items()}
+    x = filler.tensor("in:g4_r2", (2, 3, 8, 8), 0.5, 0.5)
+    with torch.no_grad():
+        gan.generator_forward(osd, x, True)
+        gan.generator_forward(osd, x, True)
+    plain, pref = os.path.join(str(tmp_path), "g.pth"), os.path.join(str(tmp_path), "g_module.pth")
+    torch.save(OrderedDict(osd), plain)
+    torch.save(OrderedDict(("module." + k, v) for k, v in osd.items()), pref)
+    outs = []
+    for path in (plain, pref):
+        g = ev.load_model(Gm.Generator(4, 2), path).to(dev).eval()
+        with torch.no_grad():
+            outs.append(g(x.to(dev)))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert np.abs(outs[0].cpu().numpy() - z["y_eval"]).max() <= 0.06
+    back = ev.save_model(g, "g_back", str(tmp_path))
+    g2 = ev.load_model(Gm.Generator(4, 2), back).to(dev).eval()
+    with torch.no_grad():
+        assert torch.equal(g2(x.to(dev)), outs[0])
+
+
+def test_evaluate_generator_loop(dev, tmp_path):
+    """eval_GAN.py:21-69 on the HIP path: per-image PSNR and their average against the fp32 oracle's numbers, whole-image
+    and halo-tiled, with the PNG dump."""
+    ev, Gm = P("evaluate"), P("models.GAN.generator")
+    sd = filler.fill_state_dict(gan.template(gan.generator_shapes(4, 2)))
+    g = Gm.Generator(4, 2)
+    g.load_state_dict(sd)
+    g.to(dev)
+    pairs, ref = [], {}
+    for i, (h, w) in enumerate([(24, 32), (40, 24), (16, 16)]):
+        lr = filler.tensor(f"ev:lr{i}", (1, 3, h, w), 0.5, 0.5)
+        hr = filler.tensor(f"ev:hr{i}", (1, 3, 4 * h, 4 * w), 0.5, 0.5)
+        pairs.append((lr.to(dev), hr.to(dev), [f"img{i}"]))
+        with torch.no_grad():
+            sr = gan.generator_forward({k: v.clone() for k, v in sd.items()}, lr, False)
+        ref[f"img{i}"] = losses.psnr(sr, hr, float(hr.max() - hr.min()))
+    for tile in (None, 16):
+        res = ev.evaluate_generator(g, pairs, tile=tile, out_dir=str(tmp_path), to_unit=lambda t: (t + 1) / 2)
+        assert list(res["psnr"]) == ["img0", "img1", "img2"]
+        for k, v in res["psnr"].items():
+            assert abs(v - ref[k]) <= 0.02, (tile, k, v, ref[k])
+        assert abs(res["avg_psnr"] - sum(ref.values()) / 3) <= 0.02
+    from PIL import Image
+    im = Image.open(os.path.join(str(tmp_path), "images", "img1.png"))
+    assert im.size == (96, 160) and im.mode == "RGB"
+    assert g.training                                            # super_resolve restores the caller's mode
