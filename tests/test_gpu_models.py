@@ -406,9 +406,26 @@ def test_dip_skip_net(dev, tag, shape, kw):
         c, cf = cos(p.grad.cpu(), ref), cos(nsd[k].grad, ref)
         if (1 - c) > 3.0 * (1 - cf) + 0.02:
             bad.append((k, round(c, 4), round(cf, 4)))
-    # the BatchNorms of the 2x2 / 3x3 bottom levels normalise 4..9 values: their few-element gradients are chaotic
-    # under ANY 16-bit storage (two bf16/fp16 implementations differ there as much as each differs from fp32)
+    # The innermost scale normalises 2x2 ... 8x8 maps at batch 1 (4 ... 64 values per channel): gradients of THAT scale's
+    # parameters are chaotic under ANY 16-bit storage (two fp16 implementations differ there as much as each differs from
+    # fp32).  Only tensors of the innermost scale may miss the bound, and even those must stay correlated.
+    inner = "1.1.7." * (len(cfg.down) - 1)            # key prefix of the deepest scale (models/DIP/skip.py nesting)
+    _record_dip(tag, bad)
+    assert all(b[0].startswith(inner) for b in bad), (inner, bad)
     assert len(bad) <= 2 and all(b[1] > 0.6 for b in bad), bad
+
+
+def _record_dip(tag, bad):
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_dip_skip.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[tag] = bad
+        json.dump(data, open(path, "w"), indent=1)
+    except OSError:
+        pass
 
 
 def _torch_forward(m, x):
@@ -469,8 +486,11 @@ def test_dip_skip_builder_flags(dev, tag, opts):
 
 
 # ----------------------------------------------------------------------------- step recipes
-def test_gan_step_vs_oracle(dev):
-    """train_GAN.py:38-71 for 2 steps on small shapes; stand-in VGG (resize 32 / crop 28)."""
+@pytest.mark.parametrize("overlap", [True, False])
+def test_gan_step_vs_oracle(dev, overlap):
+    """train_GAN.py:38-71 for 2 steps on small shapes; stand-in VGG (resize 32 / crop 28); two-stream and single-stream
+    form of the step.  |dPSNR| <= 0.02 dB (the north-star bar) and losses within 2 % at both steps; after the steps the
+    BatchNorm running statistics of both networks and every weight tensor's 2-step displacement agree with the oracle."""
     Gm, Dm, GANu, optim, steps = P("models.GAN.generator"), P("models.GAN.discriminator"), P("utils.GAN"), P("optim"), P("steps")
     gsd = filler.fill_state_dict(gan.template(gan.generator_shapes(4, 2)))
     dsd = filler.fill_state_dict(gan.template(gan.discriminator_shapes((64, 64))))
@@ -485,11 +505,30 @@ def test_gan_step_vs_oracle(dev):
     lr = filler.tensor("in:gs_lr", (4, 3, 16, 16), 0.5, 0.5)
     hr = filler.tensor("in:gs_hr", (4, 3, 64, 64))
     for it in range(2):
-        ld, lg, fake = steps.gan_step(g, d, perc, og, od, lr.to(dev), hr.to(dev))
-        rld, rlg, rfake = recipes.gan_step(st, lr, hr)
-        assert abs(ld.item() - rld) < 0.05 * max(abs(rld), 0.1), (it, ld.item(), rld)
-        assert abs(lg.item() - rlg) < 0.05 * max(abs(rlg), 0.1), (it, lg.item(), rlg)
-        assert abs(losses.psnr(fake.cpu(), hr) - losses.psnr(rfake, hr)) <= 0.05
+        cap = {}
+        ld, lg, fake = steps.gan_step(g, d, perc, og, od, lr.to(dev), hr.to(dev), overlap=overlap)
+        rld, rlg, rfake = recipes.gan_step(st, lr, hr, capture=cap)
+        assert abs(ld.item() - rld) < 0.02 * max(abs(rld), 0.1), (it, ld.item(), rld)
+        assert abs(lg.item() - rlg) < 0.02 * max(abs(rlg), 0.1), (it, lg.item(), rlg)
+        assert abs(losses.psnr(fake.cpu(), hr) - losses.psnr(rfake, hr)) <= 0.02
+        if it == 0:       # the gradients both Adam steps consumed, from identical weights (shallow net: tight bounds)
+            bad = []
+            for mod, ref in ((g, cap["g_grads"]), (d, cap["d_grads"])):
+                for k, p_ in mod.named_parameters():
+                    r = ref[k]
+                    if r.numel() == 1 or float(r.abs().max()) == 0.0 or (k.endswith("bias") and ("conv" in k) and
+                                                                          ("residual_blocks" in k or "convblocks" in k or k == "conv2.bias")):
+                        continue
+                    c, ratio = cos(p_.grad.cpu(), r), float(p_.grad.norm().cpu() / r.norm())
+                    if c < 0.985 or abs(ratio - 1) > 0.05:
+                        bad.append((k, round(c, 4), round(ratio, 4)))
+            assert not bad, bad
+    for mod, osd in ((g, st.g), (d, st.d)):
+        for k, v in mod.state_dict().items():
+            if "running_" in k:
+                assert rel_err(v.cpu(), osd[k]) < 1e-2, k
+            if "num_batches" in k:
+                assert int(v) == int(osd[k]), k
     for k, v in d.state_dict().items():          # three D forwards per step update the running statistics 3x
         if "num_batches" in k:
             assert int(v) == 6 == int(st.d[k])
