@@ -411,8 +411,7 @@ def test_dip_skip_net(dev, tag, shape, kw):
     # fp32).  Only tensors of the innermost scale may miss the bound, and even those must stay correlated.
     inner = "1.1.7." * (len(cfg.down) - 1)            # key prefix of the deepest scale (models/DIP/skip.py nesting)
     _record_dip(tag, bad)
-    assert all(b[0].startswith(inner) for b in bad), (inner, bad)
-    assert len(bad) <= 2 and all(b[1] > 0.6 for b in bad), bad
+    assert not bad, (inner, bad)      # measured round 2: no tensor misses the bound in any of the seven configurations
 
 
 def _record_dip(tag, bad):
@@ -511,18 +510,17 @@ def test_gan_step_vs_oracle(dev, overlap):
         assert abs(ld.item() - rld) < 0.02 * max(abs(rld), 0.1), (it, ld.item(), rld)
         assert abs(lg.item() - rlg) < 0.02 * max(abs(rlg), 0.1), (it, lg.item(), rlg)
         assert abs(losses.psnr(fake.cpu(), hr) - losses.psnr(rfake, hr)) <= 0.02
-        if it == 0:       # the gradients both Adam steps consumed, from identical weights (shallow net: tight bounds)
-            bad = []
-            for mod, ref in ((g, cap["g_grads"]), (d, cap["d_grads"])):
-                for k, p_ in mod.named_parameters():
-                    r = ref[k]
-                    if r.numel() == 1 or float(r.abs().max()) == 0.0 or (k.endswith("bias") and ("conv" in k) and
-                                                                          ("residual_blocks" in k or "convblocks" in k or k == "conv2.bias")):
-                        continue
-                    c, ratio = cos(p_.grad.cpu(), r), float(p_.grad.norm().cpu() / r.norm())
-                    if c < 0.985 or abs(ratio - 1) > 0.05:
-                        bad.append((k, round(c, 4), round(ratio, 4)))
-            assert not bad, bad
+        if it == 0:       # the gradients both Adam steps consumed, from identical weights, against the bf16 floor
+            from parity_util import compare_grads, prelu_ok
+            sim_cap = {}
+            sim = recipes.GanState({k: v.clone() for k, v in gsd.items()}, {k: v.clone() for k, v in dsd.items()}, vsd,
+                                   lr=1e-4, vgg_resize=32, vgg_crop=28)
+            with lowp.storage(torch.bfloat16):
+                recipes.gan_step(sim, lr, hr, capture=sim_cap)
+            bad_g, _ = compare_grads(dict((k, p_.grad) for k, p_ in g.named_parameters()), cap["g_grads"], sim_cap["g_grads"], "G:")
+            bad_d, _ = compare_grads(dict((k, p_.grad) for k, p_ in d.named_parameters()), cap["d_grads"], sim_cap["d_grads"], "D:")
+            assert not (bad_g + bad_d), bad_g + bad_d
+            assert not prelu_ok(dict((k, p_.grad) for k, p_ in g.named_parameters()), cap["g_grads"], sim_cap["g_grads"])
     for mod, osd in ((g, st.g), (d, st.d)):
         for k, v in mod.state_dict().items():
             if "running_" in k:
@@ -532,6 +530,41 @@ def test_gan_step_vs_oracle(dev, overlap):
     for k, v in d.state_dict().items():          # three D forwards per step update the running statistics 3x
         if "num_batches" in k:
             assert int(v) == 6 == int(st.d[k])
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_graphed_gan_step_equals_eager(dev, overlap):
+    """The whole train_GAN.py:38-71 step -- both HIP streams of steps.gan_step, three discriminator forwards, two
+    backward passes, both fused Adam updates with their device-side step counters, weight re-packing, every BatchNorm
+    running-statistic update -- captured ONCE in a HIP graph (steps.GraphedStep, what bench.py replays for config 3) must
+    leave bit for bit the state that the same number of eager steps leaves."""
+    Gm, Dm, GANu, optim, steps = P("models.GAN.generator"), P("models.GAN.discriminator"), P("utils.GAN"), P("optim"), P("steps")
+    gsd = filler.fill_state_dict(gan.template(gan.generator_shapes(4, 2)))
+    dsd = filler.fill_state_dict(gan.template(gan.discriminator_shapes((64, 64))))
+    lr = filler.tensor("in:gg_lr", (4, 3, 16, 16), 0.5, 0.5).to(dev)
+    hr = filler.tensor("in:gg_hr", (4, 3, 64, 64)).to(dev)
+    perc = GANu.PerceptualLoss(resize_to=32, crop=28).to(dev)
+
+    def make():
+        g, d = Gm.Generator(4, 2), Dm.Discriminator((64, 64))
+        g.load_state_dict(gsd), d.load_state_dict(dsd)
+        g.to(dev).train(), d.to(dev).train()
+        og, od = optim.FusedAdam(g.parameters(), lr=1e-3), optim.FusedAdam(d.parameters(), lr=1e-3)
+        return g, d, (lambda: steps.gan_step(g, d, perc, og, od, lr, hr, overlap=overlap))
+
+    g_e, d_e, step_e = make()
+    for _ in range(5):
+        out_e = step_e()
+    g_g, d_g, step_g = make()
+    graphed = steps.GraphedStep(step_g, warmup=2)         # 2 eager warm-up steps; capture itself executes nothing
+    for _ in range(3):
+        out_g = graphed()
+    torch.cuda.synchronize()
+    for a, b in zip(out_e, out_g):
+        assert torch.equal(a, b)
+    for me, mg in ((g_e, g_g), (d_e, d_g)):
+        for (k, a), (_, b) in zip(me.state_dict().items(), mg.state_dict().items()):
+            assert torch.equal(a, b), k
 
 
 def test_dip_step_vs_oracle(dev):
@@ -638,7 +671,8 @@ def test_rccl_single_rank_gan_step(dev):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
     sums = {}
-    for tag, extra in (("plain", dict(DSR_BENCH_CHECKSUM="1")), ("gather", dict(DSR_DIST_FORCE="1")),
+    # (plain: eager like the two distributed runs -- a graph-replayed bench takes three more warm-up steps)
+    for tag, extra in (("plain", dict(DSR_BENCH_CHECKSUM="1", DSR_GAN_GRAPH="0")), ("gather", dict(DSR_DIST_FORCE="1")),
                        ("allreduce", dict(DSR_DIST_FORCE="1", DSR_DP_FACTOR_GATHER="0"))):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", **extra)
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
