@@ -515,7 +515,8 @@ extern "C" int dsr_conv_wgrad(const dsr_conv_desc* d, const void* x, const void*
 }
 
 // ---- measurement aid: the kernel family the dispatch above selects (kept next to it so the two cannot drift far)
-static const char* gemm_name(int nb) {
+static const char* gemm_name(int nb, long long M = 0, bool fast = false, bool stats = true) {
+  if (nb > 64 && dsr_conv_gemm_use_256(M, nb, fast, stats)) return "conv_gemm_kernel<256x256>";
   return nb > 64 ? "conv_gemm_kernel<128x128>" : (nb > 16 ? "conv_gemm_kernel<128x64>" : "conv_gemm_kernel<128x16>");
 }
 extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, const dsr_epilogue* e) {
@@ -527,13 +528,17 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
     if (d->Cout <= 16 && d->stride == 1 && d->pad_mode == DSR_PAD_ZERO && d->KH * d->KW >= 9 && !stats && !ps &&
         d->KW == 9 && d->KH <= 9 && r8(d->Cin) == 64)
       return "conv_smalln_kernel";
-    return gemm_name(r8(d->Cout));
+    int OH, OW;
+    dsr_conv_out_size(d, &OH, &OW);
+    return gemm_name(r8(d->Cout), (long long)d->N * OH * OW, d->pad_mode == DSR_PAD_ZERO && r8(d->Cin) % 64 == 0, stats);
   }
   if (op == 1) {
     if (is_c64(d)) return "conv_c64_kernel";
     if (is_tail9(d)) return "conv_dgrad_toeplitz9_kernel";
     if (is_smalln_dgrad(d)) return "conv_smalln_kernel";
-    return gemm_name(r8(d->Cin));
+    // input gradient on the gather kernel: grid = the input pixels (stride 1) or one output-parity class of them (stride 2)
+    const long long Mg = (long long)d->N * ((d->H + d->stride - 1) / d->stride) * ((d->W + d->stride - 1) / d->stride);
+    return gemm_name(r8(d->Cin), Mg, r8(d->Cout) % 64 == 0 && (d->pad_mode == DSR_PAD_ZERO || d->pad == 0), false);
   }
   WgradTileArgs t;
   bool taps = false;

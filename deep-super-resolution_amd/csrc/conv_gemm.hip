@@ -32,7 +32,7 @@ struct ConvGemmLds {
 };
 
 template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA, int NSTAGE, bool SWAP>
-__global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) void conv_gemm_kernel(const ConvGemmArgs a) {
+__global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 256 * 256) ? 2 : (WGM * WGN) / 2) void conv_gemm_kernel(const ConvGemmArgs a) {
   static_assert(!DMA || FAST, "the LDS-DMA loader exists for the fast path only");
   static_assert(NSTAGE == 2 || (NSTAGE == 3 && DMA), "three stages: DMA ring only");
   constexpr int NW = WGM * WGN;                 // 4 or 8 waves; two blocks per CU either way
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
   // bias of this tile's columns: the DMA variants (which have registers to spare) request it before the K loop, so
   // its latency does not sit in the epilogue; the register-staged variants are at their occupancy edge (159 VGPRs, three
   // blocks per CU for the 128x64 tile) and read it where it is used
-  constexpr bool PRELOAD_BIAS = DMA;
+  constexpr bool PRELOAD_BIAS = DMA && NW == 4;   // (the 8-wave 256x256 variant has no registers to spare: 128 accumulators)
   float bias_r[TN][SWAP ? 4 : 1];
   auto bias_at = [&](int k, int jj) {
     const int col = n0 + wn * WN + 16 * k + (SWAP ? 4 * g + jj : r16);
@@ -284,7 +284,45 @@ __global__ __launch_bounds__(64 * WGM * WGN, NSTAGE == 3 ? 2 : (WGM * WGN) / 2) 
           for (int k = 0; k < TN; ++k) acc[i][k] = SWAP ? mfma16<DT>(fb[k], fa[i], acc[i][k]) : mfma16<DT>(fa[i], fb[k], acc[i][k]);
       }
     };
-    if constexpr (NSTAGE == 2) {
+    if constexpr (NSTAGE == 2 && NW == 8) {
+      // 256x256 tile, 8 waves of 128x64, ONE resident block per CU (two waves per SIMD, 256 registers each: 128 of them
+      // accumulators).  Per K-step and wave: 24 ds_read_b128 and 64 MFMAs (0.375 reads per MFMA; the 64x64 wave tile
+      // of the 128x128 variant needs 0.5 and saturates the LDS at full MFMA rate) and 8 DMA pieces per 64 MFMAs (half
+      // the 128x128 tile's).  The two waves of a SIMD would run in lock-step (same program, one barrier per K-step), so
+      // waves 4..7 issue their DMA between the two MFMA groups: one wave's DMA issue (60-100 cycles per piece) runs under
+      // its partner's MFMAs.  One live B set (4 fragments) and a rolling A fragment keep the loop inside 256 VGPRs.
+      const bool late_dma = wave >= NW / 2;
+      dma_step(0, 0);
+      TapStep nd = decode_step(ks > 1 ? 1 : 0);
+      for (int s = 0; s < ks; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int cur = s & 1;
+        const unsigned char* pa = sA + cur * A_STAGE + (wm * WM + r16) * 128;
+        const unsigned char* pb = sB + cur * B_STAGE + (wn * WN + r16) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int slot = ((4 * kk + g) ^ sw) << 4;
+          U4 fb[TN];
+#pragma unroll
+          for (int k = 0; k < TN; ++k) fb[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot);
+          if (kk == 0 && !late_dma && s + 1 < ks) dma_issue(nd, cur ^ 1);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const U4 fa = *reinterpret_cast<const U4*>(pa + i * 16 * 128 + slot);
+#pragma unroll
+            for (int k = 0; k < TN; ++k) acc[i][k] = SWAP ? mfma16<DT>(fb[k], fa, acc[i][k]) : mfma16<DT>(fa, fb[k], acc[i][k]);
+          }
+          if (kk == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (late_dma && s + 1 < ks) dma_issue(nd, cur ^ 1);
+            if (s + 2 < ks) nd = decode_step(s + 2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    } else if constexpr (NSTAGE == 2) {
       dma_step(0, 0);
       TapStep nd = decode_step(ks > 1 ? 1 : 0);      // the tap table read of the NEXT step is kept out of the loop body's
       for (int s = 0; s < ks; ++s) {                 // head: it shares the LDS counter with the fragment reads
@@ -665,7 +703,7 @@ static void launch_variant(dim3 grid, const ConvGemmArgs& b, hipStream_t st) {
     }
   }
   // statistics launches, and the register-staged variants (measured 10 % slower with the channel-major epilogue)
-  launch_swap<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE, false>(grid, b, st);
+  if constexpr (BM < 256) launch_swap<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE, false>(grid, b, st);
 }
 
 static bool env_on(const char* name) {   // tuning switches, default on ("0" turns one off)
@@ -691,10 +729,12 @@ static void launch_one(const ConvGemmArgs& a, hipStream_t st) {
         return;
       }
     }
-    if (fast)
-      launch_variant<DT, BM, BN, WGM, WGN, true, false, 2>(grid, b, st);
-    else
-      launch_variant<DT, BM, BN, WGM, WGN, false, false, 2>(grid, b, st);
+    if constexpr (BM < 256) {       // (the 256x256 tile exists as the LDS-DMA fast path only; dispatch_dt guarantees it)
+      if (fast)
+        launch_variant<DT, BM, BN, WGM, WGN, true, false, 2>(grid, b, st);
+      else
+        launch_variant<DT, BM, BN, WGM, WGN, false, false, 2>(grid, b, st);
+    }
   }
 }
 
@@ -703,10 +743,15 @@ static void dispatch_dt(const ConvGemmArgs& a, hipStream_t st) {
   if (a.NB > 64) {
     // big problems: 256x128 tiles, 8 waves, three-stage DMA ring, one block per CU (needs >= 2 blocks per CU of work)
     // measured: 5-12 % SLOWER than two resident 128x128 blocks on every config-3 layer, so it is off unless asked for
-    static const bool use_big = [] { const char* e = getenv("DSR_CONV_BIG"); return e && e[0] == '1'; }();
+    const bool use_big = true;
     const bool fast = a.pad_mode == DSR_PAD_ZERO && (a.CU & 7) == 0 && a.ntaps > 0;
     const long long big_tiles = (long long)((a.M + 255) / 256) * ((a.NB + 127) / 128);
-    if (use_big && fast && big_tiles >= 512)
+    // 256x256 tile, 8 waves of 128x64 (2 x 4), two stages, one block per CU: per MFMA half the LDS fragment reads
+    // (0.375 ds_read_b128 per MFMA instead of 0.5) and half the DMA pieces of the 128x128 tile
+    const int big_mode = dsr_conv_big_mode();
+    if (dsr_conv_gemm_use_256(a.M, a.NB, fast && env_on("DSR_CONV_DMA"), (a.flags & DSR_F_STATS) != 0))
+      launch_one<DT, 256, 256, 2, 4>(a, st);
+    else if (use_big && big_mode == 1 && fast && big_tiles >= 512)
       launch_one<DT, 256, 128, 4, 2, 3>(a, st);
     else
       launch_one<DT, 128, 128, 2, 2>(a, st);      // (8 waves of 64x32 were tried: LDS-bound, 35 % slower)

@@ -438,10 +438,12 @@ class ConvBNAct(torch.autograd.Function):
                                           int(ctx.train), _stream()))
         dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape)
         db = None
-        if ctx.has_bias:
-            # a bias in front of a train-mode BatchNorm has an analytically zero gradient (the reference holds
-            # ~1e-9 rounding noise there); in eval mode it is the column sum of dy.
-            db = torch.zeros(cout, dtype=torch.float32, device=dev) if ctx.train else _colsum(dy, cout)
+        if ctx.has_bias and not ctx.train:
+            # a bias in front of a train-mode BatchNorm has an analytically zero gradient (the reference holds ~1e-9
+            # rounding noise there): no gradient is produced for it at all -- Adam leaves such a parameter exactly where
+            # a zero gradient would (m = v = 0 => no update), and 47 zero-fill launches per GAN step disappear.
+            # In eval mode it is the column sum of dy.
+            db = _colsum(dy, cout)
         dres = dout if ctx.has_res else None
         return dx, dw, db, dgamma, dbeta, None, None, None, dprelu, dres, None
 

@@ -241,6 +241,8 @@ def test_conv_bn_act(dev, case):
         assert rel_err(from_nhwc(resg.grad.cpu(), cout), resr.grad) < 1e-6
     if not train:
         assert rel_err(bg.grad.cpu(), br.grad) < tol
+    else:
+        assert bg.grad is None      # analytically zero in front of a train-mode BatchNorm: not produced (functional.ConvBNAct)
 
 
 @pytest.mark.parametrize("actn,cout", [("tanh", 3), ("sigmoid", 3), ("none", 5)])
@@ -464,3 +466,54 @@ def test_first_layer_fused_backward(dev, n, h, w, actn):
     assert rel_err(dw_f, wr.grad) < 2.5e-2 and rel_err(db_f, br.grad) < 2.5e-2
     # fused vs unfused: the fused kernel multiplies in fp32 and rounds g once, the unfused path stores g in bf16 first
     assert rel_err(dw_f, dw_u) < 5e-3 and rel_err(db_f, db_u) < 5e-3
+
+
+@pytest.mark.parametrize("op", ["fwd", "dgrad", "dgrad_s2"])
+def test_conv_256x256_tile_equals_128x128(dev, op):
+    """The 256x256-tile variant of the gather kernel (8 waves of 128x64, one block per CU; conv_gemm.hip) walks K in the
+    same order as the 128x128 one, so it must reproduce it BIT FOR BIT; DSR_CONV_BIG=0 selects the 128x128 tile."""
+    import ctypes as C
+    import os
+    L = P("_lib")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n, h, w, cin, cout, stride = (3, 160, 167, 128, 256, 1) if op != "dgrad_s2" else (3, 320, 334, 256, 64, 2)
+    if op == "dgrad":
+        cin, cout = 256, 128
+    d = L.ConvDesc(L.BF16, n, h, w, cin, cout, 3, 3, stride, 1, 0)
+    oh, ow = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    g = torch.Generator(device="cpu").manual_seed(7)
+    wt = ((torch.rand(cout, cin, 3, 3, generator=g) - 0.5) * 0.1).to(dev)
+    wf = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 0), dtype=torch.bfloat16, device=dev)
+    wd = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 1), dtype=torch.bfloat16, device=dev)
+    L.check(lib.dsr_conv_pack_weight(C.byref(d), wt.data_ptr(), wf.data_ptr(), wd.data_ptr(), st))
+    x = (torch.rand(n, h, w, cin, generator=g) - 0.5).to(torch.bfloat16).to(dev)
+    dy = (torch.rand(n, oh, ow, cout, generator=g) - 0.5).to(torch.bfloat16).to(dev)
+    bias = (torch.rand(cout, generator=g) - 0.5).to(dev)
+    outs = []
+    old = os.environ.get("DSR_CONV_BIG")
+    try:
+        for mode in ("0", "2"):
+            os.environ["DSR_CONV_BIG"] = mode
+            if op == "fwd":
+                y = torch.full((n, oh, ow, cout), float("nan"), dtype=torch.bfloat16, device=dev)
+                ep = L.Epilogue(L.ACT_RELU, 0.0, None, bias.data_ptr(), None, 0, None)
+                name = lib.dsr_conv_kernel_name(C.byref(d), 0, C.byref(ep)).decode()
+                L.check(lib.dsr_conv_fwd(C.byref(d), x.data_ptr(), wf.data_ptr(), C.byref(ep), y.data_ptr(), st))
+                outs.append(y)
+            else:
+                dx = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
+                wsz = lib.dsr_conv_dgrad_workspace(C.byref(d))
+                ws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=dev)
+                name = lib.dsr_conv_kernel_name(C.byref(d), 1, None).decode()
+                L.check(lib.dsr_conv_dgrad(C.byref(d), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), ws.data_ptr(), wsz, st))
+                outs.append(dx)
+            assert ("256x256" in name) == (mode == "2"), (mode, name)
+    finally:
+        if old is None:
+            os.environ.pop("DSR_CONV_BIG", None)
+        else:
+            os.environ["DSR_CONV_BIG"] = old
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])

@@ -74,7 +74,8 @@ def main():
         y = torch.empty(n, oh, ow, r8(cout), dtype=torch.bfloat16, device=dev)
         rows = lib.dsr_conv_stats_rows(C.byref(d))
         part = torch.empty((rows + 64) * 2 * r8(cout), dtype=torch.float32, device=dev)
-        ep = L.Epilogue(0, 0.0, None, bias.data_ptr(), part.data_ptr() if (cout > 16 and cin > 8) else None, 0, None)   # first layers carry no BatchNorm
+        nostats = os.environ.get("MB_NOSTATS", "0") == "1"      # VGG-style launches: no BatchNorm statistics epilogue
+        ep = L.Epilogue(0, 0.0, None, bias.data_ptr(), part.data_ptr() if (cout > 16 and cin > 8 and not nostats) else None, 0, None)   # first layers carry no BatchNorm
         tf = timeit(lambda: L.check(lib.dsr_conv_fwd(C.byref(d), x.data_ptr(), wf.data_ptr(), C.byref(ep), y.data_ptr(), st)))
         dy = (torch.rand_like(y.float()) - 0.5).to(torch.bfloat16)
         dx = torch.empty_like(x)
