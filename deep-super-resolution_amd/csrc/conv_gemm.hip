@@ -697,7 +697,9 @@ static void launch_swap(dim3 grid, const ConvGemmArgs& b, hipStream_t st) {
 template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA, int NSTAGE>
 static void launch_variant(dim3 grid, const ConvGemmArgs& b, hipStream_t st) {
   if constexpr (DMA) {
-    if (!(b.flags & DSR_F_STATS)) {
+    // (the 256x256 tile has no register room for the pixel-major epilogue: it takes its statistics from the
+    //  channel-major accumulators -- 16-lane shuffle sums -- as well)
+    if (!(b.flags & DSR_F_STATS) || BM >= 256) {
       launch_swap<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE, true>(grid, b, st);
       return;
     }

@@ -61,8 +61,8 @@ struct ConvGemmArgs {
 };
 
 void dsr_launch_conv_gemm(const ConvGemmArgs& a, int dtype, hipStream_t st);
-// 256x256-tile variant of the gather kernel (conv_gemm.hip): LDS-DMA fast path, N a multiple of 256, no BatchNorm
-// statistics epilogue, and at least one tile per CU.  Shared by the dispatcher and by dsr_conv_kernel_name().
+// 256x256-tile variant of the gather kernel (conv_gemm.hip): LDS-DMA fast path, N a multiple of 256 and at least one
+// tile per CU.  Shared by the dispatcher and by dsr_conv_kernel_name().
 // DSR_CONV_BIG: 0 = 128x128 tiles only, 1 = the 256x128 three-stage experiment, 2 (default) = 256x256 where it applies.
 static inline int dsr_conv_big_mode(void) {
   const char* e = getenv("DSR_CONV_BIG");            // read per call: tests switch it inside one process
@@ -70,7 +70,8 @@ static inline int dsr_conv_big_mode(void) {
 }
 static inline bool dsr_conv_gemm_use_256(long long M, int NB, bool fast, bool stats) {
   const long long tiles = ((M + 255) / 256) * ((NB + 255) / 256);
-  return dsr_conv_big_mode() == 2 && fast && NB % 256 == 0 && !stats && tiles >= 256;
+  (void)stats;   // both epilogues exist on the 256x256 tile (statistics from the channel-major accumulators)
+  return dsr_conv_big_mode() == 2 && fast && NB % 256 == 0 && tiles >= 256;
 }
 
 bool dsr_launch_conv_gemm_persist(const ConvGemmArgs& a, int dtype, hipStream_t st);   // conv_gemm_persist.hip

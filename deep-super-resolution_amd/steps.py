@@ -24,7 +24,9 @@ _side_streams = {}
 def _side_stream(device):
     key = (device.type, device.index)
     if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
+        import os
+        # DSR_SIDE_PRIORITY (tuning switch): HIP stream priority of the D-half stream, 0 = default, -1 = high
+        _side_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("DSR_SIDE_PRIORITY", "0")))
     return _side_streams[key]
 
 

@@ -468,7 +468,7 @@ def test_first_layer_fused_backward(dev, n, h, w, actn):
     assert rel_err(dw_f, dw_u) < 5e-3 and rel_err(db_f, db_u) < 5e-3
 
 
-@pytest.mark.parametrize("op", ["fwd", "dgrad", "dgrad_s2"])
+@pytest.mark.parametrize("op", ["fwd", "fwd_stats", "dgrad", "dgrad_s2"])
 def test_conv_256x256_tile_equals_128x128(dev, op):
     """The 256x256-tile variant of the gather kernel (8 waves of 128x64, one block per CU; conv_gemm.hip) walks K in the
     same order as the 128x128 one, so it must reproduce it BIT FOR BIT; DSR_CONV_BIG=0 selects the 128x128 tile."""
@@ -490,17 +490,22 @@ def test_conv_256x256_tile_equals_128x128(dev, op):
     x = (torch.rand(n, h, w, cin, generator=g) - 0.5).to(torch.bfloat16).to(dev)
     dy = (torch.rand(n, oh, ow, cout, generator=g) - 0.5).to(torch.bfloat16).to(dev)
     bias = (torch.rand(cout, generator=g) - 0.5).to(dev)
-    outs = []
+    outs, stats = [], []
     old = os.environ.get("DSR_CONV_BIG")
     try:
         for mode in ("0", "2"):
             os.environ["DSR_CONV_BIG"] = mode
-            if op == "fwd":
+            if op in ("fwd", "fwd_stats"):
                 y = torch.full((n, oh, ow, cout), float("nan"), dtype=torch.bfloat16, device=dev)
-                ep = L.Epilogue(L.ACT_RELU, 0.0, None, bias.data_ptr(), None, 0, None)
+                rows = lib.dsr_conv_stats_rows(C.byref(d))
+                part = torch.full(((rows + 64) * 2 * cout,), float("nan"), dtype=torch.float32, device=dev)
+                ep = L.Epilogue(L.ACT_RELU if op == "fwd" else L.ACT_NONE, 0.0, None, bias.data_ptr(),
+                                part.data_ptr() if op == "fwd_stats" else None, 0, None)
                 name = lib.dsr_conv_kernel_name(C.byref(d), 0, C.byref(ep)).decode()
                 L.check(lib.dsr_conv_fwd(C.byref(d), x.data_ptr(), wf.data_ptr(), C.byref(ep), y.data_ptr(), st))
                 outs.append(y)
+                if op == "fwd_stats":     # BatchNorm statistics: per-channel sum and sum of squares over all pixels
+                    stats.append(part[:rows * 2 * cout].reshape(rows, 2, cout).double().sum(0))
             else:
                 dx = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
                 wsz = lib.dsr_conv_dgrad_workspace(C.byref(d))
@@ -517,3 +522,8 @@ def test_conv_256x256_tile_equals_128x128(dev, op):
     torch.cuda.synchronize()
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0], outs[1])
+    if stats:    # same fp32 accumulators, summed in a different order (channel-major vs pixel-major epilogue)
+        assert torch.isfinite(stats[0]).all()
+        assert float((stats[0] - stats[1]).abs().max() / stats[0].abs().max()) < 1e-6
+        ref = torch.stack([outs[0].float().double().sum((0, 1, 2)), (outs[0].float().double() ** 2).sum((0, 1, 2))])
+        assert float((stats[1] - ref).abs().max() / ref.abs().max()) < 2e-3      # (y is the bf16-rounded accumulator)

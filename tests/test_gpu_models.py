@@ -403,6 +403,9 @@ def test_dip_skip_net(dev, tag, shape, kw):
         ref = osd[k].grad
         if ref.abs().sum() < 1e-3 * max(1.0, ref.numel() ** 0.5):
             continue
+        if p.grad is None:        # conv bias in front of a train-mode BatchNorm: analytically zero, not produced (the oracle
+            assert k.endswith(".bias") and osd[k].dim() == 1      # holds cancellation noise there, large at 2x2 populations)
+            continue
         c, cf = cos(p.grad.cpu(), ref), cos(nsd[k].grad, ref)
         if (1 - c) > 3.0 * (1 - cf) + 0.02:
             bad.append((k, round(c, 4), round(cf, 4)))
