@@ -523,7 +523,9 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
   if (!d || check_desc(d)) return "invalid";
   const bool ps = e && e->pixel_shuffle, nchw = e && e->out_nchw_f32, stats = e && e->stats_partial;
   if (op == 0) {
-    if (((is_c64(d) && !ps) || is_c64_wide(d)) && !nchw) return "conv_c64_kernel";
+    // (named like the symbols of a rocprof summary: <mode 0> statistics epilogue, <1> plain, <2> folded inference epilogue)
+    if (((is_c64(d) && !ps) || is_c64_wide(d)) && !nchw)
+      return (e && (e->bn_scale || e->residual)) ? "conv_c64_kernel<2>" : (stats ? "conv_c64_kernel<0>" : "conv_c64_kernel<1>");
     if (is_cin8(d, e)) return "conv_cin8_kernel";
     if (d->Cout <= 16 && d->stride == 1 && d->pad_mode == DSR_PAD_ZERO && d->KH * d->KW >= 9 && !stats && !ps &&
         d->KW == 9 && d->KH <= 9 && r8(d->Cin) == 64)
@@ -533,7 +535,7 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
     return gemm_name(r8(d->Cout), (long long)d->N * OH * OW, d->pad_mode == DSR_PAD_ZERO && r8(d->Cin) % 64 == 0, stats);
   }
   if (op == 1) {
-    if (is_c64(d)) return "conv_c64_kernel";
+    if (is_c64(d)) return "conv_c64_kernel<1>";
     if (is_tail9(d)) return "conv_dgrad_toeplitz9_kernel";
     if (is_smalln_dgrad(d)) return "conv_smalln_kernel";
     // input gradient on the gather kernel: grid = the input pixels (stride 1) or one output-parity class of them (stride 2)
@@ -544,6 +546,13 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
   bool taps = false;
   bool toep = false;
   int ych = tile_plan(d, t, &taps, &toep);
-  if (ych > 0) return toep ? "conv_wgrad_toeplitz9_kernel" : (taps ? "conv_wgrad_taps_kernel" : "conv_wgrad_tile_kernel");
+  if (ych > 0) {
+    if (toep) return "conv_wgrad_toeplitz9_kernel";
+    if (taps) return "conv_wgrad_taps_kernel";
+    // the three tile-resident kernels are different symbols in a rocprof summary: name them as it does
+    if (d->KH == 3 && d->stride == 1) return "conv_wgrad_dma_kernel";
+    if (d->KH == 3) return "conv_wgrad_dma_s2_kernel";
+    return "conv_wgrad_tile_kernel<1x1>";
+  }
   return "conv_wgrad_kernel";
 }

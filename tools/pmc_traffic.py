@@ -13,7 +13,12 @@ def family(name):
     m = re.search(r"conv_gemm_kernel<\(int\)\d+, \(int\)(\d+), \(int\)(\d+)", name) or re.search(r"conv_gemm_kernel<\d+, (\d+), (\d+)", name)
     if m:
         return f"conv_gemm_kernel<{m.group(1)}x{m.group(2)}>"
-    for k in ("conv_c64_kernel", "conv_smalln_kernel", "conv_wgrad_tile_kernel", "conv_wgrad_taps_kernel", "conv_wgrad_kernel"):
+    m = re.search(r"conv_c64_kernel<(?:\(int\))?\d+, (?:\(int\))?(\d+)>", name)
+    if m:
+        return f"conv_c64_kernel<{m.group(1)}>"            # same labels as dsr_conv_kernel_name()
+    if "conv_wgrad_tile_kernel" in name:
+        return "conv_wgrad_tile_kernel<1x1>"
+    for k in ("conv_wgrad_dma_s2_kernel", "conv_wgrad_dma_kernel", "conv_smalln_kernel", "conv_wgrad_taps_kernel", "conv_wgrad_kernel"):
         if k in name:
             return k
     return re.sub(r"<.*", "", name.split("(")[0]).strip()
