@@ -91,7 +91,7 @@ extern "C" int dsr_conv_fwd_affine_supported(const dsr_conv_desc* d) {
 extern "C" int dsr_conv_stats_rows(const dsr_conv_desc* d) {
   int OH, OW;
   if (dsr_conv_out_size(d, &OH, &OW)) return -1;
-  if (is_c64(d) || is_c64_wide(d)) return dsr_c64_tiles(d->N, OH, OW);   // one statistics row per spatial tile
+  if (is_c64(d) || is_c64_wide(d)) return dsr_c64_stat_rows(d->N, OH, OW, r8(d->Cout));   // one statistics row per persistent block
   long long M = (long long)d->N * OH * OW;
   return (int)((M + 127) / 128);
 }

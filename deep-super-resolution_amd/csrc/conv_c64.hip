@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
+  float stat_acc = 0.f;
   for (; t < a.ntiles; t += tstep, buf ^= 1) {
     STAMP(0);
     // my DMA of this tile is done; after the barrier everyone's is, and every wave is past the previous tile.
@@ -396,8 +397,10 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     asm volatile("" ::: "memory");
     STAMP(5);
     if (do_stats && tid < 128) {
+      // BatchNorm statistics: summed over this block's tiles in a register, ONE partial row per block at the end (512
+      // rows per launch instead of one per tile -- 8192 at config 3 -- so the finalize kernel needs no compaction pass)
       const int which = tid >> 6, col = tid & 63;
-      a.stats[((size_t)t * 2 + which) * a.CoutP + c0 + col] = sStat[0][which][col] + sStat[1][which][col];
+      stat_acc += sStat[0][which][col] + sStat[1][which][col];
     }
     {
       // exactly 2 stores per thread (see the wait above).  Scalar part: byte offset of the tile origin in y.
@@ -425,6 +428,8 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     }
     STAMP(6);
   }
+  if (do_stats && tid < 128)      // (every block owns at least one tile: grid.x <= ntiles)
+    a.stats[((size_t)blockIdx.x * 2 + (tid >> 6)) * a.CoutP + c0 + (tid & 63)] = stat_acc;
 #ifdef DSR_C64_STAMPS
   if (blockIdx.x == 37 && blockIdx.y == 0 && (tid == 0 || tid == 192))
     for (int q = 0; q < 8; ++q) g_c64_stamps[(tid ? 8 : 0) + q] = st_acc[q];
@@ -434,6 +439,11 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
 // statistics rows written by one launch (= spatial tiles)
 int dsr_c64_tiles(int N, int H, int W) {
   return N * ((H + 1) / 2) * ((W + 31) / 32);
+}
+// BatchNorm statistics rows written by one launch: one per persistent block of a 64-channel output slice
+int dsr_c64_stat_rows(int N, int H, int W, int CoutP) {
+  const int ntiles = dsr_c64_tiles(N, H, W), per_slice = 512 / (CoutP / 64);
+  return ntiles < per_slice ? ntiles : per_slice;
 }
 
 void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st) {

@@ -147,6 +147,7 @@ struct C64Args {
   unsigned x_bytes, y_bytes;
 };
 int dsr_c64_tiles(int N, int H, int W);
+int dsr_c64_stat_rows(int N, int H, int W, int CoutP);
 void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st);
 
 struct Cin8Args {

@@ -259,6 +259,128 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int tiles,
   if (c == 0 && num_batches != nullptr) *num_batches += updates;
 }
 
+// ---- single-launch finalize for up to DSR_FINALIZE_PAR_ROWS partial rows: 64 channels x 4 row-lanes per block.  Row-lane
+// q sums rows q, q+4, ... in that order with 8 loads in flight (double accumulators); the four partial sums are combined
+// in a fixed order through LDS, so the result does not depend on timing.  Replaces compact_rows + the serial finalize
+// (two launches and a boundary) wherever the producers emit few rows: the persistent c64 kernel (one row per block),
+// and the small problems (config 2, DIP).
+#define DSR_FINALIZE_PAR_ROWS 512      // measured (tools/_bin/fin_probe.py): one launch wins up to ~512 rows (6.6 us vs ~10 us for
+                                       // compaction + finalize); at 2048 rows its latency chain loses (18.6 us vs 8 us)
+#define DSR_FINALIZE_PAR_ROWS_BWD 64   // three slices per row: loses from 512 rows on (36.7 us)
+template <int NS>
+__device__ __forceinline__ void par_column_sums(const float* __restrict__ partial, int rows, int row_stride, int slice_stride,
+                                                int c, bool active, double (&tot)[NS], double* red /* [NS][4][64] */) {
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  double s[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) s[k] = 0.0;
+  if (active) {
+    int r = ry;
+    for (; r + 28 < rows; r += 32) {
+      float v[NS][8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) v[k][u] = partial[(size_t)(r + 4 * u) * row_stride + k * slice_stride + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] += (double)v[k][u];
+    }
+    for (; r < rows; r += 4)
+#pragma unroll
+      for (int k = 0; k < NS; ++k) s[k] += (double)partial[(size_t)r * row_stride + k * slice_stride + c];
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) red[(k * 4 + ry) * 64 + cx] = s[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+    tot[k] = red[(k * 4 + 0) * 64 + cx] + red[(k * 4 + 1) * 64 + cx] + red[(k * 4 + 2) * 64 + cx] + red[(k * 4 + 3) * 64 + cx];
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_par_kernel(
+    const float* __restrict__ partial, int tiles, int stride, int C, float count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+    long long* __restrict__ num_batches, float momentum, float eps, int updates, float* __restrict__ scale,
+    float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ rstd_out, int Cp) {
+  __shared__ double red[2 * 4 * 64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double tot[2];
+  par_column_sums<2>(partial, tiles, 2 * stride, stride, c, c < C, tot, red);
+  if (threadIdx.x >= 64 || c >= Cp) return;
+  if (c >= C) {   // padded channels
+    scale[c] = 0.f;
+    shift[c] = 0.f;
+    mean_out[c] = 0.f;
+    rstd_out[c] = 0.f;
+    return;
+  }
+  const double mean = tot[0] / count;
+  double var = tot[1] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  mean_out[c] = (float)mean;
+  rstd_out[c] = rstd;
+  if (running_mean != nullptr) {
+    const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+    float rm = running_mean[c], rv = running_var[c];
+    for (int u = 0; u < updates; ++u) {
+      rm = (1.f - momentum) * rm + momentum * (float)mean;
+      rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+    }
+    running_mean[c] = rm;
+    running_var[c] = rv;
+  }
+  if (c == 0 && num_batches != nullptr) *num_batches += updates;
+}
+
+// backward: partial rows [blocks][3][Cp] = (sum g, sum g*xhat, PReLU terms).  One block of 64 channels at a time; the PReLU
+// slope gradient (a sum over channels) is only produced by the single-block case Cp <= 64 (the generator's layers).
+__global__ __launch_bounds__(256) void bn_bwd_finalize_par_kernel(const float* __restrict__ partial, int blocks, int C, int Cp,
+                                                                  float count, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, float* __restrict__ dprelu,
+                                                                  float* __restrict__ c1, float* __restrict__ c2) {
+  __shared__ double red[3 * 4 * 64];
+  const int cx = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + cx;
+  double tot[3];
+  par_column_sums<3>(partial, blocks, 3 * Cp, Cp, c, c < Cp, tot, red);
+  if (threadIdx.x < 64 && c < Cp) {
+    if (c < C) {
+      if (dgamma) dgamma[c] = (float)tot[1];
+      if (dbeta) dbeta[c] = (float)tot[0];
+    }
+    c1[c] = c < C ? (float)(tot[0] / count) : 0.f;
+    c2[c] = c < C ? (float)(tot[1] / count) : 0.f;
+  }
+  if (dprelu) {        // (Cp <= 64: one block) channel sum in a fixed order
+    __syncthreads();
+    if (threadIdx.x < 64) red[cx] = c < C ? tot[2] : 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double s = 0.0;
+      for (int i = 0; i < 64; ++i) s += red[i];
+      dprelu[0] = (float)s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_rows_par_kernel(const float* __restrict__ partial, int rows, int row_stride,
+                                                           int col_offset, int C, float scale, float* __restrict__ out,
+                                                           int accumulate) {
+  __shared__ double red[4 * 64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double tot[1];
+  par_column_sums<1>(partial + col_offset, rows, row_stride, 0, c, c < C, tot, red);
+  if (threadIdx.x >= 64 || c >= C) return;
+  const float v = (float)(tot[0] * (double)scale);
+  out[c] = accumulate ? out[c] + v : v;
+}
+
 // eval mode: scale/shift from the running statistics
 __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ running_mean, const float* __restrict__ running_var,
@@ -828,6 +950,11 @@ extern "C" int dsr_pw_scratch_rows(void) { return DSR_COMPACT_ROWS; }
 extern "C" int dsr_pw_sum_rows(const float* partial, int rows, int row_stride, int col_offset, int C, float scale, float* out,
                      int accumulate, int compact, hipStream_t st) {
   DSR_REQUIRE(partial && out && rows >= 0 && row_stride > 0 && col_offset >= 0 && C > 0, "sum_rows: null pointer or bad shape");
+  if (rows > 32 && rows <= DSR_FINALIZE_PAR_ROWS && row_stride > 1) {      // one launch: parallel over 4 row-lanes
+    hipLaunchKernelGGL(sum_rows_par_kernel, dim3(nblk(C, 64)), dim3(256), 0, st, partial, rows, row_stride, col_offset, C, scale,
+                       out, accumulate);
+    return dsr_launch_status("dsr_pw_sum_rows");
+  }
   if (compact && row_stride > 1) partial = compact_rows(partial, rows, row_stride, &rows, st);
   hipLaunchKernelGGL(sum_rows_kernel, dim3(nblk(C, 128)), dim3(128), 0, st, partial, rows, row_stride, col_offset, C,
                      scale, out, accumulate);
@@ -837,6 +964,11 @@ extern "C" int dsr_pw_bn_finalize(const float* partial, int tiles, int stride, i
                         const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, int updates,
                         float* scale, float* shift, float* mean, float* rstd, hipStream_t st) {
   DSR_REQUIRE(partial && gamma && beta && scale && shift && mean && rstd && tiles > 0 && C > 0 && Cp >= C && stride >= Cp && count > 0.f && updates >= 0, "bn_finalize: null pointer or bad shape");
+  if (tiles > 32 && tiles <= DSR_FINALIZE_PAR_ROWS) {
+    hipLaunchKernelGGL(bn_finalize_par_kernel, dim3(nblk(Cp, 64)), dim3(256), 0, st, partial, tiles, stride, C, count, gamma, beta,
+                       rm, rv, nbt, momentum, eps, updates, scale, shift, mean, rstd, Cp);
+    return dsr_launch_status("dsr_pw_bn_finalize");
+  }
   partial = compact_rows(partial, tiles, 2 * stride, &tiles, st);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(Cp, 64)), dim3(64), 0, st, partial, tiles, stride, C, count, gamma,
                      beta, rm, rv, nbt, momentum, eps, updates, scale, shift, mean, rstd, Cp);
@@ -890,6 +1022,11 @@ extern "C" int dsr_pw_bn_act_bwd_reduce(int dtype, const void* dout, const void*
 extern "C" int dsr_pw_bn_bwd_finalize(const float* partial, int blocks, int C, int Cp, float count, float* dgamma, float* dbeta,
                             float* dprelu, float* c1, float* c2, hipStream_t st) {
   DSR_REQUIRE(partial && c1 && c2 && blocks > 0 && C > 0 && Cp >= C && count > 0.f, "bn_bwd_finalize: null pointer or bad shape");
+  if (blocks > 32 && blocks <= DSR_FINALIZE_PAR_ROWS_BWD && (!dprelu || Cp <= 64)) {
+    hipLaunchKernelGGL(bn_bwd_finalize_par_kernel, dim3(nblk(Cp, 64)), dim3(256), 0, st, partial, blocks, C, Cp, count, dgamma,
+                       dbeta, dprelu, c1, c2);
+    return dsr_launch_status("dsr_pw_bn_bwd_finalize");
+  }
   partial = compact_rows(partial, blocks, 3 * Cp, &blocks, st);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, blocks, C, Cp, count, dgamma, dbeta,
                      dprelu, c1, c2);
