@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libdsr_hip.so")
 
-ABI_VERSION = 2          # bumped whenever a signature in include/dsr_hip.h changes; checked against the loaded library
+ABI_VERSION = 3          # bumped whenever a signature in include/dsr_hip.h changes; checked against the loaded library
 BF16, F16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_PRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_ELU = range(7)
 PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = range(3)
@@ -94,6 +94,8 @@ SIGNATURES = {
     "dsr_box_copy": (_I, [_P, _P] + [_I] * 16 + [_P]),
     "dsr_downsample_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dsr_downsample_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dsr_ssim_blocks": (_I, [_I, _I, _I]),
+    "dsr_ssim_f32": (_I, [_P, _P, _I, _I, _I, _F, _P, _P]),
 }
 
 _lib = None
@@ -104,7 +106,7 @@ LAUNCH_LOG = None
 _NO_LAUNCH = ("dsr_last_error", "dsr_abi_version", "dsr_conv_kernel_name", "dsr_conv_fwd_affine_supported",
               "dsr_conv_first_bwd_supported", "dsr_conv_first_bwd_workspace", "dsr_conv_out_size", "dsr_conv_stats_rows",
               "dsr_conv_packed_elems", "dsr_conv_dgrad_workspace", "dsr_conv_wgrad_workspace", "dsr_pw_scratch_rows",
-              "dsr_pw_reduce_blocks", "dsr_linear_fwd_workspace")
+              "dsr_pw_reduce_blocks", "dsr_linear_fwd_workspace", "dsr_ssim_blocks")
 
 
 class _Lib:

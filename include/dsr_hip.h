@@ -227,6 +227,14 @@ int dsr_downsample_fwd(const float* x, const float* kern, float* y, int NC, int 
 int dsr_downsample_bwd(const float* dy, const float* kern, float* dx, int NC, int H, int W, int k, int f, int p,
                        dsr_stream_t s);
 
+/* SSIM as the reference's scripts measure it (torchmetrics StructuralSimilarityIndexMeasure at train_GAN.py:31,111,
+ * eval_GAN.py:31,48): Gaussian 11x11 sigma 1.5 window, K1 0.01, K2 0.03, per plane (planes = N*C fp32 H x W images),
+ * window positions inside the image.  Writes dsr_ssim_blocks(planes, H, W) partial sums; their total divided by
+ * planes * (H-10) * (W-10) is the mean SSIM. */
+int dsr_ssim_blocks(int planes, int H, int W);
+int dsr_ssim_f32(const float* img1, const float* img2, int planes, int H, int W, float data_range, float* partial,
+                 dsr_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

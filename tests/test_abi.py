@@ -42,7 +42,7 @@ def test_ctypes_signatures_match_header(so):
     for name, (_, args) in L.SIGNATURES.items():
         assert len(args) == decl[name], (name, len(args), decl[name])
     L.lib()
-    assert L.lib().dsr_abi_version() == L.ABI_VERSION == 2
+    assert L.lib().dsr_abi_version() == L.ABI_VERSION == 3
 
 
 def test_host_side_descriptor_checks(so):
@@ -136,6 +136,9 @@ def test_bad_arguments_return_codes_not_crashes(so):
         lambda: lib.dsr_box_copy(N, N, 1, 2, 2, 4, 4, 4, 8, 0, 0, 0, 4, 4, 8, 0, 0, 0, st),
         lambda: lib.dsr_downsample_fwd(N, N, N, 3, 8, 8, 4, 2, 1, st),
         lambda: lib.dsr_downsample_bwd(N, N, N, 3, 8, 8, 4, 2, 1, st),
+        lambda: lib.dsr_ssim_f32(N, N, 3, 32, 32, 1.0, N, st),
+        lambda: lib.dsr_ssim_f32(one, one, 3, 8, 32, 1.0, one, st),           # image smaller than the 11x11 window
+        lambda: lib.dsr_ssim_f32(one, one, 3, 32, 32, 0.0, one, st),          # data_range
     ]
     for i, call in enumerate(calls):
         rc = call()
@@ -146,6 +149,7 @@ def test_bad_arguments_return_codes_not_crashes(so):
     assert lib.dsr_conv_wgrad_workspace(N) == 0 and lib.dsr_conv_first_bwd_workspace(N) == 0
     assert lib.dsr_conv_stats_rows(N) < 0 and lib.dsr_conv_fwd_affine_supported(N) == 0
     assert lib.dsr_conv_kernel_name(N, 0, N) == b"invalid"
+    assert lib.dsr_ssim_blocks(3, 8, 32) == 0 and lib.dsr_ssim_blocks(3, 42, 18) == 3 * 4 * 1
 
 
 def test_entry_point_without_return_does_not_compile(tmp_path):

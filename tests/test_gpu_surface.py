@@ -11,7 +11,7 @@ import pytest
 import torch
 import torch.nn.functional as TF
 
-from oracle import dip, downsampler, filler, gan, losses, lowp, recipes, vgg
+from oracle import dip, downsampler, filler, gan, losses, lowp, metrics, recipes, vgg
 
 pytestmark = pytest.mark.gpu
 PKG = "deep-super-resolution_amd"
@@ -276,7 +276,7 @@ def test_evaluate_generator_loop(dev, tmp_path):
     g = Gm.Generator(4, 2)
     g.load_state_dict(sd)
     g.to(dev)
-    pairs, ref = [], {}
+    pairs, ref, ref_ssim = [], {}, {}
     for i, (h, w) in enumerate([(24, 32), (40, 24), (16, 16)]):
         lr = filler.tensor(f"ev:lr{i}", (1, 3, h, w), 0.5, 0.5)
         hr = filler.tensor(f"ev:hr{i}", (1, 3, 4 * h, 4 * w), 0.5, 0.5)
@@ -284,13 +284,36 @@ def test_evaluate_generator_loop(dev, tmp_path):
         with torch.no_grad():
             sr = gan.generator_forward({k: v.clone() for k, v in sd.items()}, lr, False)
         ref[f"img{i}"] = losses.psnr(sr, hr, float(hr.max() - hr.min()))
+        ref_ssim[f"img{i}"] = metrics.ssim(sr, hr, 1.0)
     for tile in (None, 16):
         res = ev.evaluate_generator(g, pairs, tile=tile, out_dir=str(tmp_path), to_unit=lambda t: (t + 1) / 2)
-        assert list(res["psnr"]) == ["img0", "img1", "img2"]
+        assert list(res["psnr"]) == ["img0", "img1", "img2"] == list(res["ssim"])
         for k, v in res["psnr"].items():
             assert abs(v - ref[k]) <= 0.02, (tile, k, v, ref[k])
         assert abs(res["avg_psnr"] - sum(ref.values()) / 3) <= 0.02
+        for k, v in res["ssim"].items():
+            assert abs(v - ref_ssim[k]) <= 2e-3, (tile, k, v, ref_ssim[k])
+        assert abs(res["avg_ssim"] - sum(ref_ssim.values()) / 3) <= 2e-3
     from PIL import Image
     im = Image.open(os.path.join(str(tmp_path), "images", "img1.png"))
     assert im.size == (96, 160) and im.mode == "RGB"
     assert g.training                                            # super_resolve restores the caller's mode
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 40, 52), (1, 1, 11, 11), (1, 3, 97, 33)])
+def test_ssim_kernel_vs_oracle(dev, shape):
+    """dsr_ssim_f32 (Gaussian 11x11, sigma 1.5, K1 0.01, K2 0.03; SSIM(data_range=1.) of eval_GAN.py:31) against the float64
+    restatement in oracle/metrics.py, plus the metric's defining properties: identical images give exactly 1, and it is
+    symmetric in its arguments."""
+    ev = P("evaluate")
+    a = filler.tensor("ssim:a" + str(shape), shape, 0.5, 0.5)
+    b = (a + filler.tensor("ssim:n" + str(shape), shape, 0.15)).clamp(0, 1)
+    ref = metrics.ssim(a, b, 1.0)
+    got = ev.ssim(a.to(dev), b.to(dev), 1.0)
+    assert abs(got - ref) <= 1e-4, (got, ref)
+    assert abs(ev.ssim(b.to(dev), a.to(dev), 1.0) - got) <= 1e-6
+    assert abs(ev.ssim(a.to(dev), a.to(dev), 1.0) - 1.0) <= 1e-6
+    if shape[2] > 11:
+        assert 0.0 < got < 1.0
+    with pytest.raises(RuntimeError):
+        ev.ssim(a.to(dev)[..., :10], b.to(dev)[..., :10])

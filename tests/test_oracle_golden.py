@@ -275,3 +275,16 @@ def test_vgg_preprocess_matches_torch_antialias():
     assert y.shape == (2, 3, 28, 28)
     x2 = T("in:vggpre2", (1, 3, 16, 16)).float()
     assert vgg.preprocess(x2, 32, 28).shape == (1, 3, 28, 28)
+
+
+def test_ssim_restatement_properties():
+    """oracle/metrics.ssim (PARITY UNPINNED: torchmetrics is absent and the reference holds no fixture): the published
+    definition's properties -- 1 for identical images, symmetric, decreasing with added noise, window normalised."""
+    from oracle import metrics
+    a = T("ssim:o_a", (2, 3, 24, 30), 0.5, 0.5).float()
+    n1 = T("ssim:o_n", (2, 3, 24, 30), 0.05).float()
+    assert abs(float(metrics.gaussian_window().sum()) - 1.0) < 1e-12
+    assert abs(metrics.ssim(a, a) - 1.0) < 1e-12
+    s1, s2 = metrics.ssim(a, a + n1), metrics.ssim(a, a + 3 * n1)
+    assert 0.0 < s2 < s1 < 1.0
+    assert abs(metrics.ssim(a + n1, a) - s1) < 1e-12
