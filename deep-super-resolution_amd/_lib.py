@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libdsr_hip.so")
 
-ABI_VERSION = 3          # bumped whenever a signature in include/dsr_hip.h changes; checked against the loaded library
+ABI_VERSION = 4          # bumped whenever a signature in include/dsr_hip.h changes; checked against the loaded library
 BF16, F16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_PRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_ELU = range(7)
 PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = range(3)
@@ -60,7 +60,7 @@ SIGNATURES = {
     "dsr_pw_channel_stats": (_I, [_I, _P, _Z, _I, _I, _I, _P, _P]),
     "dsr_pw_bn_act_fwd": (_I, [_I, _P, _P, _P, _P, _P, _Z, _I, _I, _F, _P, _P]),
     "dsr_pw_bn_act_bwd_reduce": (_I, [_I, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _F, _P, _P, _P]),
-    "dsr_pw_bn_bwd_finalize": (_I, [_P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
+    "dsr_pw_bn_bwd_finalize": (_I, [_P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dsr_pw_bn_act_bwd_apply": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _F, _P, _I, _P]),
     "dsr_pw_act_bwd": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P]),
     "dsr_pw_act_bwd_nchw": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -10,6 +10,8 @@
 //                                                      models/DIP/utils.py:68; skip.py:94
 //   residual add x + z                                 generator.py:23,74
 //   PixelShuffle(2) backward (un-shuffle)              generator.py:32,38
+#include <stdlib.h>
+
 #include "dsr_common.h"
 #include "dsr_kernels.h"
 #include "../../include/dsr_hip.h"
@@ -341,7 +343,8 @@ __global__ __launch_bounds__(256) void bn_finalize_par_kernel(
 // backward: partial rows [blocks][3][Cp] = (sum g, sum g*xhat, PReLU terms).  One block of 64 channels at a time; the PReLU
 // slope gradient (a sum over channels) is only produced by the single-block case Cp <= 64 (the generator's layers).
 __global__ __launch_bounds__(256) void bn_bwd_finalize_par_kernel(const float* __restrict__ partial, int blocks, int C, int Cp,
-                                                                  float count, float* __restrict__ dgamma,
+                                                                  float count, const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, float* __restrict__ dgamma,
                                                                   float* __restrict__ dbeta, float* __restrict__ dprelu,
                                                                   float* __restrict__ c1, float* __restrict__ c2) {
   __shared__ double red[3 * 4 * 64];
@@ -350,6 +353,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_par_kernel(const float* _
   double tot[3];
   par_column_sums<3>(partial, blocks, 3 * Cp, Cp, c, c < Cp, tot, red);
   if (threadIdx.x < 64 && c < Cp) {
+    if (c < C) tot[1] = (double)rstd[c] * (tot[1] - (double)mean[c] * tot[0]);      // sum g*y -> sum g*xhat
     if (c < C) {
       if (dgamma) dgamma[c] = (float)tot[1];
       if (dbeta) dbeta[c] = (float)tot[0];
@@ -449,7 +453,27 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const unsigned short
 // Every thread owns one 8-channel chunk and walks pixels: the per-channel affine parameters are loaded ONCE into
 // registers (a one-vector-per-thread version spends more load instructions on parameters than on payload and
 // reaches only ~0.8 TB/s).
-template <int DT>
+// 8 consecutive per-channel fp32 parameters as two 16-byte loads (eight scalar loads per array put a chain of ~30 dependent
+// L2 round trips in front of a kernel that only streams for 20-30 us)
+typedef __attribute__((ext_vector_type(4))) float PF4;
+__device__ __forceinline__ void load8(const float* __restrict__ src, int c0, float (&dst)[8]) {
+  const PF4 a = *reinterpret_cast<const PF4*>(src + c0), b = *reinterpret_cast<const PF4*>(src + c0 + 4);
+  dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+  dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+}
+// streaming accesses: tensors far beyond the 256 MiB Infinity Cache stream fastest with nontemporal accesses, cache-sized
+// ones with plain ones (tools/stream_probe.hip: 6.0-6.6 vs 5.2-5.9 TB/s at 537 MB, 6.0-6.4 vs 6.5-7.1 TB/s at 67 MB)
+template <bool NT>
+__device__ __forceinline__ U4 ld16(const unsigned short* p) {
+  return NT ? __builtin_nontemporal_load(reinterpret_cast<const U4*>(p)) : *reinterpret_cast<const U4*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st16(unsigned short* p, const U4& v) {
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<U4*>(p)); else *reinterpret_cast<U4*>(p) = v;
+}
+#define DSR_PW_NT_BYTES (192ull << 20)   // operand tensors of at least this size use the nontemporal path
+
+template <int DT, bool NT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const unsigned short* __restrict__ y,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
@@ -462,29 +486,51 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const unsigned short* _
   if (rr >= rpi) return;
   const float slope = prelu ? prelu[0] : slope_v;
   float sc[8], sh[8];
+  if (scale) {
+    load8(scale, ch * 8, sc);
+    load8(shift, ch * 8, sh);
+  } else {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    sc[k] = scale ? scale[ch * 8 + k] : 1.f;
-    sh[k] = scale ? shift[ch * 8 + k] : 0.f;
+    for (int k = 0; k < 8; ++k) sc[k] = 1.f, sh[k] = 0.f;
   }
-  const size_t stride = (size_t)gridDim.x * rpi;
-  for (size_t p = (size_t)blockIdx.x * rpi + rr; p < P; p += stride) {
+  auto apply = [&](const U4& vy, const U4& vr) {
     float f[8], r[8];
-    unpack8<DT>(*reinterpret_cast<const U4*>(y + p * Cp + ch * 8), f);
-    if (residual) unpack8<DT>(*reinterpret_cast<const U4*>(residual + p * Cp + ch * 8), r);
+    unpack8<DT>(vy, f);
+    if (residual) unpack8<DT>(vr, r);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       float v = act_apply(act, f[k] * sc[k] + sh[k], slope);
       if (residual) v += r[k];
       f[k] = v;
     }
-    *reinterpret_cast<U4*>(out + p * Cp + ch * 8) = pack8<DT>(f);
+    return pack8<DT>(f);
+  };
+  // two pixel rows per iteration: all loads of an iteration are issued before the first use
+  const size_t stride = (size_t)gridDim.x * rpi;
+  size_t p = (size_t)blockIdx.x * rpi + rr;
+  const size_t coff = (size_t)ch * 8;
+  for (; p + stride < P; p += 2 * stride) {
+    const size_t o0 = p * Cp + coff, o1 = (p + stride) * Cp + coff;
+    const U4 y0 = ld16<NT>(y + o0), y1 = ld16<NT>(y + o1);
+    U4 r0 = y0, r1 = y1;
+    if (residual) {
+      r0 = ld16<NT>(residual + o0);
+      r1 = ld16<NT>(residual + o1);
+    }
+    st16<NT>(out + o0, apply(y0, r0));
+    st16<NT>(out + o1, apply(y1, r1));
+  }
+  if (p < P) {
+    const size_t o0 = p * Cp + coff;
+    const U4 y0 = ld16<NT>(y + o0);
+    const U4 r0 = residual ? ld16<NT>(residual + o0) : y0;
+    st16<NT>(out + o0, apply(y0, r0));
   }
 }
 
 // backward of out = act(scale*y + shift) [+ residual]; g = dout * act'(z).
 // pass 1: per-channel partial sums of g, g*xhat and the PReLU slope gradient sum(dout * z * [z<0]).
-template <int DT>
+template <int DT, bool NT, int UNR>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     const unsigned short* __restrict__ dout, const unsigned short* __restrict__ y, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd, size_t P, int Cp,
@@ -495,35 +541,51 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
   const int rpi = 256 / cpr;
   const int ch = tid % cpr, rr = tid / cpr;
   const float slope = prelu ? prelu[0] : slope_v;
+  // slot 1 holds sum g*y (the raw conv output), not sum g*xhat: xhat = (y - mean) * rstd is affine in y, so the finalize
+  // kernel forms sum g*xhat = rstd * (sum g*y - mean * sum g) in double precision and this kernel keeps two parameter
+  // arrays less in registers (134 -> under 100 VGPRs: 3 -> 5 waves per SIMD)
   float sg[8], sgx[8], sp[8];
-  float csc[8], csh[8], cm[8], cr[8];
+  float csc[8], csh[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    sg[k] = sgx[k] = sp[k] = 0.f;
-    int c = (ch < cpr ? ch : 0) * 8 + k;
-    csc[k] = scale[c];
-    csh[k] = shift[c];
-    cm[k] = mean[c];
-    cr[k] = rstd[c];
-  }
+  for (int k = 0; k < 8; ++k) sg[k] = sgx[k] = sp[k] = 0.f;
+  load8(scale, ch * 8, csc);
+  load8(shift, ch * 8, csh);
   size_t p0 = (size_t)blockIdx.x * rows_per_block;
   size_t p1 = p0 + rows_per_block;
   if (p1 > P) p1 = P;
-  if (rr < rpi) {
-    for (size_t p = p0 + rr; p < p1; p += rpi) {
-      float d[8], f[8];
-      unpack8<DT>(*reinterpret_cast<const U4*>(dout + p * Cp + ch * 8), d);
-      unpack8<DT>(*reinterpret_cast<const U4*>(y + p * Cp + ch * 8), f);
+  auto accum = [&](const U4& vd, const U4& vy) {
+    float d[8], f[8];
+    unpack8<DT>(vd, d);
+    unpack8<DT>(vy, f);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        float z = f[k] * csc[k] + csh[k];
-        float o = act_apply(act, z, slope);
-        float gg = d[k] * act_grad_from_out(act, (act == DSR_ACT_LEAKY || act == DSR_ACT_PRELU) ? z : o, slope);
-        float xh = (f[k] - cm[k]) * cr[k];
-        sg[k] += gg;
-        sgx[k] += gg * xh;
-        if (act == DSR_ACT_PRELU && z < 0.f) sp[k] += d[k] * z;
+    for (int k = 0; k < 8; ++k) {
+      const float z = f[k] * csc[k] + csh[k];
+      const float o = act_apply(act, z, slope);
+      const float gg = d[k] * act_grad_from_out(act, (act == DSR_ACT_LEAKY || act == DSR_ACT_PRELU) ? z : o, slope);
+      sg[k] += gg;
+      sgx[k] += gg * f[k];
+      if (act == DSR_ACT_PRELU && z < 0.f) sp[k] += d[k] * z;
+    }
+  };
+  if (rr < rpi) {
+    const size_t coff = (size_t)ch * 8;
+    size_t p = p0 + rr;
+    if constexpr (UNR == 2) {
+      for (; p + rpi < p1; p += 2 * rpi) {       // two pixel rows in flight (summed in row order: deterministic)
+        const size_t o0 = p * Cp + coff, o1 = (p + rpi) * Cp + coff;
+        const U4 d0 = ld16<NT>(dout + o0), y0 = ld16<NT>(y + o0), d1 = ld16<NT>(dout + o1), y1 = ld16<NT>(y + o1);
+        accum(d0, y0);
+        accum(d1, y1);
       }
+    } else {
+      for (; p + rpi < p1; p += rpi) {
+        const size_t o0 = p * Cp + coff;
+        accum(ld16<NT>(dout + o0), ld16<NT>(y + o0));
+      }
+    }
+    if (p < p1) {
+      const size_t o0 = p * Cp + coff;
+      accum(ld16<NT>(dout + o0), ld16<NT>(y + o0));
     }
   }
 #pragma unroll
@@ -544,6 +606,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
 
 // finalize: dgamma = sum g*xhat, dbeta = sum g, dprelu = sum over channels; c1 = dbeta/n, c2 = dgamma/n
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int C, int Cp, float count,
+                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ dprelu, float* __restrict__ c1, float* __restrict__ c2) {
   __shared__ double sp[256];
@@ -573,6 +636,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int bl
       p += (double)partial[((size_t)b * 3 + 2) * Cp + cc];
     }
     if (cc < C) {
+      gx = (double)rstd[cc] * (gx - (double)mean[cc] * g);      // sum g*y -> sum g*xhat
       if (dgamma) dgamma[cc] = (float)gx;
       if (dbeta) dbeta[cc] = (float)g;
       acc_p += p;
@@ -591,7 +655,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int bl
 
 // pass 2: dy = scale * (g - c1 - xhat * c2)      (scale = gamma * rstd), folded per channel into
 //   dy = A*g + B*y + C,  A = scale, B = -scale*c2*rstd, C = scale*(c2*mean*rstd - c1);  eval mode: dy = scale*g.
-template <int DT>
+template <int DT, bool NT>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const unsigned short* __restrict__ dout, const unsigned short* __restrict__ y, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -603,32 +667,49 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
   if (rr >= rpi) return;
   const float slope = prelu ? prelu[0] : slope_v;
   float sc[8], sh[8], cb[8], cc[8];
+  load8(scale, ch * 8, sc);
+  load8(shift, ch * 8, sh);
+  if (train) {
+    float k1[8], k2[8], mu[8], rs[8];
+    load8(c1, ch * 8, k1);
+    load8(c2, ch * 8, k2);
+    load8(mean, ch * 8, mu);
+    load8(rstd, ch * 8, rs);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int c = ch * 8 + k;
-    sc[k] = scale[c];
-    sh[k] = shift[c];
-    if (train) {
-      cb[k] = -sc[k] * c2[c] * rstd[c];
-      cc[k] = sc[k] * (c2[c] * mean[c] * rstd[c] - c1[c]);
-    } else {
-      cb[k] = 0.f;
-      cc[k] = 0.f;
+    for (int k = 0; k < 8; ++k) {
+      cb[k] = -sc[k] * k2[k] * rs[k];
+      cc[k] = sc[k] * (k2[k] * mu[k] * rs[k] - k1[k]);
     }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cb[k] = cc[k] = 0.f;
   }
   const bool lin = act == DSR_ACT_LEAKY || act == DSR_ACT_PRELU;
-  const size_t stride = (size_t)gridDim.x * rpi;
-  for (size_t p = (size_t)blockIdx.x * rpi + rr; p < P; p += stride) {
+  auto apply = [&](const U4& vd, const U4& vy) {
     float d[8], f[8];
-    unpack8<DT>(*reinterpret_cast<const U4*>(dout + p * Cp + ch * 8), d);
-    unpack8<DT>(*reinterpret_cast<const U4*>(y + p * Cp + ch * 8), f);
+    unpack8<DT>(vd, d);
+    unpack8<DT>(vy, f);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float z = f[k] * sc[k] + sh[k];
       const float gg = d[k] * act_grad_from_out(act, lin ? z : act_apply(act, z, slope), slope);
       f[k] = sc[k] * gg + cb[k] * f[k] + cc[k];
     }
-    *reinterpret_cast<U4*>(dy + p * Cp + ch * 8) = pack8<DT>(f);
+    return pack8<DT>(f);
+  };
+  const size_t stride = (size_t)gridDim.x * rpi;
+  size_t p = (size_t)blockIdx.x * rpi + rr;
+  const size_t coff = (size_t)ch * 8;
+  for (; p + stride < P; p += 2 * stride) {
+    const size_t o0 = p * Cp + coff, o1 = (p + stride) * Cp + coff;
+    const U4 d0 = ld16<NT>(dout + o0), y0 = ld16<NT>(y + o0), d1 = ld16<NT>(dout + o1), y1 = ld16<NT>(y + o1);
+    st16<NT>(dy + o0, apply(d0, y0));
+    st16<NT>(dy + o1, apply(d1, y1));
+  }
+  if (p < P) {
+    const size_t o0 = p * Cp + coff;
+    const U4 d0 = ld16<NT>(dout + o0), y0 = ld16<NT>(y + o0);
+    st16<NT>(dy + o0, apply(d0, y0));
   }
 }
 
@@ -636,7 +717,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
 // dy[conv layout] = dout * act'(out), where out is the stored activation OUTPUT (valid for slope > 0).
 // pixshuf: out/dout are [N][2H][2W][Cq] and dy is [N][H][W][4*C] with channel 4c+2i+j <- pixel (2h+i,2w+j).
 // Also emits per-block partial rows: [blocks][2][CyP] = (bias grad column sums, PReLU-slope grad terms).
-template <int DT>
+template <int DT, bool NT>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const unsigned short* __restrict__ dout,
                                                       const unsigned short* __restrict__ out,
                                                       unsigned short* __restrict__ dy, int N, int H, int W, int CyP,
@@ -662,13 +743,40 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const unsigned short* __re
   size_t p0 = (size_t)blockIdx.x * rows_per_block;
   size_t p1 = p0 + rows_per_block;
   if (p1 > P) p1 = P;
-  if (rr < rpi) {
+  auto one = [&](const float (&d)[8], const float (&o)[8], size_t p) {
+    float g[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      g[k] = d[k] * act_grad_from_out(act, o[k], slope) + poison;
+      sb[k] += g[k];
+      if (act == DSR_ACT_PRELU && o[k] < 0.f) sp[k] += d[k] * (o[k] / slope);
+      sp[k] += poison;
+    }
+    st16<NT>(dy + p * CyP + ch * 8, pack8<DT>(g));
+  };
+  if (rr < rpi && !pixshuf) {
+    size_t p = p0 + rr;
+    for (; p + rpi < p1; p += 2 * rpi) {        // two pixel rows in flight
+      const U4 d0 = ld16<NT>(dout + p * CoP + ch * 8), o0 = ld16<NT>(out + p * CoP + ch * 8);
+      const U4 d1 = ld16<NT>(dout + (p + rpi) * CoP + ch * 8), o1 = ld16<NT>(out + (p + rpi) * CoP + ch * 8);
+      float d[8], o[8];
+      unpack8<DT>(d0, d);
+      unpack8<DT>(o0, o);
+      one(d, o, p);
+      unpack8<DT>(d1, d);
+      unpack8<DT>(o1, o);
+      one(d, o, p + rpi);
+    }
+    if (p < p1) {
+      float d[8], o[8];
+      unpack8<DT>(ld16<NT>(dout + p * CoP + ch * 8), d);
+      unpack8<DT>(ld16<NT>(out + p * CoP + ch * 8), o);
+      one(d, o, p);
+    }
+  } else if (rr < rpi) {
     for (size_t p = p0 + rr; p < p1; p += rpi) {
       float d[8], o[8];
-      if (!pixshuf) {
-        unpack8<DT>(*reinterpret_cast<const U4*>(dout + p * CoP + ch * 8), d);
-        unpack8<DT>(*reinterpret_cast<const U4*>(out + p * CoP + ch * 8), o);
-      } else {
+      {
         int w = (int)(p % W);
         int h = (int)((p / W) % H);
         int n = (int)(p / ((size_t)W * H));
@@ -687,15 +795,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const unsigned short* __re
           o[4 + sub] = h2f<DT>((unsigned short)(ov >> 16));
         }
       }
-      float g[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        g[k] = d[k] * act_grad_from_out(act, o[k], slope) + poison;
-        sb[k] += g[k];
-        if (act == DSR_ACT_PRELU && o[k] < 0.f) sp[k] += d[k] * (o[k] / slope);
-        sp[k] += poison;
-      }
-      *reinterpret_cast<U4*>(dy + p * CyP + ch * 8) = pack8<DT>(g);
+      one(d, o, p);
     }
   }
   if (partial == nullptr) return;
@@ -984,7 +1084,7 @@ extern "C" int dsr_pw_bn_eval_affine(const float* gamma, const float* beta, cons
 extern "C" int dsr_pw_reduce_blocks(size_t P, int* rows_per_block) {
   if (!rows_per_block) return dsr_fail(DSR_E_ARG, "reduce_blocks: null rows_per_block");
   // enough blocks to fill 256 CUs a few times over, at least 64 rows each
-  size_t target = 2048;
+  static const size_t target = [] { const char* e = getenv("DSR_PW_REDUCE_BLOCKS"); return (size_t)(e ? atoi(e) : 2048); }();
   size_t rpb = (P + target - 1) / target;
   if (rpb < 64) rpb = 64;
   *rows_per_block = (int)rpb;
@@ -997,16 +1097,37 @@ extern "C" int dsr_pw_channel_stats(int dtype, const void* x, size_t P, int Cp, 
                                       (const unsigned short*)x, P, Cp, rpb, partial));
   return dsr_launch_status("dsr_pw_channel_stats");
 }
+// grid of the row-walking pointwise kernels; env DSR_PW_BLOCKS / DSR_PW_NT override the policy (tuning).
+// Measured (tools/microbench_pw.py, profiles/r02_pointwise_sweep.txt): tensors beyond the Infinity Cache stream best
+// nontemporally from many short blocks (16384), cache-sized ones with plain accesses from ~4096 blocks.
+static unsigned pw_grid(size_t P, int rpi, bool nt) {
+  static const int forced = [] { const char* e = getenv("DSR_PW_BLOCKS"); return e ? atoi(e) : 0; }();
+  if (forced > 0) return (unsigned)forced;
+  const size_t cap = nt ? 16384 : 4096;
+  size_t want = (P + (size_t)rpi - 1) / (size_t)rpi;      // at least one pixel row per thread
+  return (unsigned)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+static bool pw_nontemporal(size_t P, int Cp) {
+  static const int forced = [] { const char* e = getenv("DSR_PW_NT"); return e ? atoi(e) : -1; }();
+  if (forced >= 0) return forced != 0;
+  return P * (size_t)Cp * 2 >= DSR_PW_NT_BYTES;
+}
 extern "C" int dsr_pw_bn_act_fwd(int dtype, const void* y, const float* scale, const float* shift, const void* residual, void* out,
                        size_t P, int Cp, int act, float slope, const float* prelu, hipStream_t st) {
   DSR_REQUIRE(y && out && DSR_DTYPE_OK(dtype) && P > 0 && DSR_CP_OK(Cp) && (!scale == !shift), "bn_act_fwd: null pointer or bad shape");
   DSR_REQUIRE(act != DSR_ACT_PRELU || prelu, "bn_act_fwd: PReLU needs its weight pointer");
   const int rpi = 256 / (Cp / 8);
-  size_t want = (P + (size_t)rpi * 8 - 1) / ((size_t)rpi * 8);     // >= 8 pixels per thread amortise the parameter loads
-  unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
-  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<DT>), dim3(blocks), dim3(256), 0, st,
-                                      (const unsigned short*)y, scale, shift, (const unsigned short*)residual,
-                                      (unsigned short*)out, P, Cp, act, slope, prelu));
+  const bool nt = pw_nontemporal(P, Cp);
+  const unsigned blocks = pw_grid(P, rpi, nt);
+  if (nt) {
+    DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<DT, true>), dim3(blocks), dim3(256), 0, st,
+                                        (const unsigned short*)y, scale, shift, (const unsigned short*)residual,
+                                        (unsigned short*)out, P, Cp, act, slope, prelu));
+  } else {
+    DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<DT, false>), dim3(blocks), dim3(256), 0, st,
+                                        (const unsigned short*)y, scale, shift, (const unsigned short*)residual,
+                                        (unsigned short*)out, P, Cp, act, slope, prelu));
+  }
   return dsr_launch_status("dsr_pw_bn_act_fwd");
 }
 extern "C" int dsr_pw_bn_act_bwd_reduce(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
@@ -1014,22 +1135,31 @@ extern "C" int dsr_pw_bn_act_bwd_reduce(int dtype, const void* dout, const void*
                               float slope, const float* prelu, float* partial, hipStream_t st) {
   DSR_REQUIRE(dout && y && scale && shift && mean && rstd && partial && DSR_DTYPE_OK(dtype) && P > 0 && DSR_CP_OK(Cp) && blocks > 0 && rpb > 0, "bn_act_bwd_reduce: null pointer or bad shape");
   DSR_REQUIRE(act != DSR_ACT_PRELU || prelu, "bn_act_bwd_reduce: PReLU needs its weight pointer");
-  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DT>), dim3(blocks), dim3(256), 0, st,
-                                      (const unsigned short*)dout, (const unsigned short*)y, scale, shift, mean, rstd, P,
-                                      Cp, rpb, act, slope, prelu, partial));
+  static const int unr = [] { const char* e = getenv("DSR_PW_REDUCE_UNROLL"); return e ? atoi(e) : 2; }();
+#define LAUNCH_RED(NTV, U)                                                                                                  \
+  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DT, NTV, U>), dim3(blocks), dim3(256), 0, st,               \
+                                      (const unsigned short*)dout, (const unsigned short*)y, scale, shift, mean, rstd, P, \
+                                      Cp, rpb, act, slope, prelu, partial))
+  if (pw_nontemporal(P, Cp)) {
+    if (unr == 2) { LAUNCH_RED(true, 2); } else { LAUNCH_RED(true, 1); }
+  } else {
+    if (unr == 2) { LAUNCH_RED(false, 2); } else { LAUNCH_RED(false, 1); }
+  }
+#undef LAUNCH_RED
   return dsr_launch_status("dsr_pw_bn_act_bwd_reduce");
 }
-extern "C" int dsr_pw_bn_bwd_finalize(const float* partial, int blocks, int C, int Cp, float count, float* dgamma, float* dbeta,
-                            float* dprelu, float* c1, float* c2, hipStream_t st) {
-  DSR_REQUIRE(partial && c1 && c2 && blocks > 0 && C > 0 && Cp >= C && count > 0.f, "bn_bwd_finalize: null pointer or bad shape");
+extern "C" int dsr_pw_bn_bwd_finalize(const float* partial, int blocks, int C, int Cp, float count, const float* mean,
+                            const float* rstd, float* dgamma, float* dbeta, float* dprelu, float* c1, float* c2,
+                            hipStream_t st) {
+  DSR_REQUIRE(partial && mean && rstd && c1 && c2 && blocks > 0 && C > 0 && Cp >= C && count > 0.f, "bn_bwd_finalize: null pointer or bad shape");
   if (blocks > 32 && blocks <= DSR_FINALIZE_PAR_ROWS_BWD && (!dprelu || Cp <= 64)) {
-    hipLaunchKernelGGL(bn_bwd_finalize_par_kernel, dim3(nblk(Cp, 64)), dim3(256), 0, st, partial, blocks, C, Cp, count, dgamma,
-                       dbeta, dprelu, c1, c2);
+    hipLaunchKernelGGL(bn_bwd_finalize_par_kernel, dim3(nblk(Cp, 64)), dim3(256), 0, st, partial, blocks, C, Cp, count, mean,
+                       rstd, dgamma, dbeta, dprelu, c1, c2);
     return dsr_launch_status("dsr_pw_bn_bwd_finalize");
   }
   partial = compact_rows(partial, blocks, 3 * Cp, &blocks, st);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, blocks, C, Cp, count, dgamma, dbeta,
-                     dprelu, c1, c2);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, blocks, C, Cp, count, mean, rstd, dgamma,
+                     dbeta, dprelu, c1, c2);
   return dsr_launch_status("dsr_pw_bn_bwd_finalize");
 }
 extern "C" int dsr_pw_bn_act_bwd_apply(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
@@ -1038,11 +1168,17 @@ extern "C" int dsr_pw_bn_act_bwd_apply(int dtype, const void* dout, const void* 
   DSR_REQUIRE(dout && y && scale && shift && mean && rstd && dy && (!train || (c1 && c2)) && DSR_DTYPE_OK(dtype) && P > 0 && DSR_CP_OK(Cp), "bn_act_bwd_apply: null pointer or bad shape");
   DSR_REQUIRE(act != DSR_ACT_PRELU || prelu, "bn_act_bwd_apply: PReLU needs its weight pointer");
   const int rpi = 256 / (Cp / 8);
-  size_t want = (P + (size_t)rpi * 8 - 1) / ((size_t)rpi * 8);
-  unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
-  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DT>), dim3(blocks), dim3(256), 0, st,
-                                      (const unsigned short*)dout, (const unsigned short*)y, scale, shift, mean, rstd, c1,
-                                      c2, (unsigned short*)dy, P, Cp, act, slope, prelu, train));
+  const bool nt = pw_nontemporal(P, Cp);
+  const unsigned blocks = pw_grid(P, rpi, nt);
+  if (nt) {
+    DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DT, true>), dim3(blocks), dim3(256), 0, st,
+                                        (const unsigned short*)dout, (const unsigned short*)y, scale, shift, mean, rstd, c1,
+                                        c2, (unsigned short*)dy, P, Cp, act, slope, prelu, train));
+  } else {
+    DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DT, false>), dim3(blocks), dim3(256), 0, st,
+                                        (const unsigned short*)dout, (const unsigned short*)y, scale, shift, mean, rstd, c1,
+                                        c2, (unsigned short*)dy, P, Cp, act, slope, prelu, train));
+  }
   return dsr_launch_status("dsr_pw_bn_act_bwd_apply");
 }
 extern "C" int dsr_pw_act_bwd(int dtype, const void* dout, const void* out, void* dy, int N, int H, int W, int CyP, int CoP,
@@ -1052,9 +1188,15 @@ extern "C" int dsr_pw_act_bwd(int dtype, const void* dout, const void* out, void
   DSR_REQUIRE(act != DSR_ACT_PRELU || prelu, "act_bwd: PReLU needs its weight pointer");
   // the derivative is taken from the stored OUTPUT, which identifies the branch only for a positive slope
   DSR_REQUIRE(act != DSR_ACT_LEAKY || slope > 0.f, "act_bwd: LeakyReLU slope %g must be > 0 (the activation gradient is derived from the stored output)", (double)slope);
-  DT_SWITCH(dtype, hipLaunchKernelGGL((act_bwd_kernel<DT>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dout,
-                                      (const unsigned short*)out, (unsigned short*)dy, N, H, W, CyP, CoP, pixshuf, act,
-                                      slope, prelu, rpb, partial));
+  if (pw_nontemporal((size_t)N * H * W, CyP)) {
+    DT_SWITCH(dtype, hipLaunchKernelGGL((act_bwd_kernel<DT, true>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dout,
+                                        (const unsigned short*)out, (unsigned short*)dy, N, H, W, CyP, CoP, pixshuf, act,
+                                        slope, prelu, rpb, partial));
+  } else {
+    DT_SWITCH(dtype, hipLaunchKernelGGL((act_bwd_kernel<DT, false>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dout,
+                                        (const unsigned short*)out, (unsigned short*)dy, N, H, W, CyP, CoP, pixshuf, act,
+                                        slope, prelu, rpb, partial));
+  }
   return dsr_launch_status("dsr_pw_act_bwd");
 }
 extern "C" int dsr_pw_act_bwd_nchw(int dtype, const float* dout, const float* out, void* dy, int N, int C, int H, int W, int Cp,

@@ -430,8 +430,8 @@ class ConvBNAct(torch.autograd.Function):
         check(lib.dsr_pw_bn_act_bwd_reduce(_dt(x), _ptr(dout), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean),
                                            _ptr(rstd), p, cp, blocks, rpb, ctx.act, slope, _ptr(prelu), _ptr(part),
                                            _stream()))
-        check(lib.dsr_pw_bn_bwd_finalize(_ptr(part), blocks, cout, cp, float(p), _ptr(dgamma), _ptr(dbeta),
-                                         _ptr(dprelu), _ptr(c1), _ptr(c2), _stream()))
+        check(lib.dsr_pw_bn_bwd_finalize(_ptr(part), blocks, cout, cp, float(p), _ptr(mean), _ptr(rstd), _ptr(dgamma),
+                                         _ptr(dbeta), _ptr(dprelu), _ptr(c1), _ptr(c2), _stream()))
         dy = torch.empty_like(y)
         check(lib.dsr_pw_bn_act_bwd_apply(_dt(x), _ptr(dout), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
                                           _ptr(c1), _ptr(c2), _ptr(dy), p, cp, ctx.act, slope, _ptr(prelu),
@@ -937,8 +937,8 @@ class BNAct(torch.autograd.Function):
         part = torch.empty((blocks + _scr()) * 3 * cp, dtype=torch.float32, device=dev)
         check(lib.dsr_pw_bn_act_bwd_reduce(_dt(x), _ptr(dout), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
                                            p, cp, blocks, rpb, ctx.act, slope, None, _ptr(part), _stream()))
-        check(lib.dsr_pw_bn_bwd_finalize(_ptr(part), blocks, c, cp, float(p), _ptr(dgamma), _ptr(dbeta), None, _ptr(c1),
-                                         _ptr(c2), _stream()))
+        check(lib.dsr_pw_bn_bwd_finalize(_ptr(part), blocks, c, cp, float(p), _ptr(mean), _ptr(rstd), _ptr(dgamma),
+                                         _ptr(dbeta), None, _ptr(c1), _ptr(c2), _stream()))
         dx = torch.empty_like(x)
         check(lib.dsr_pw_bn_act_bwd_apply(_dt(x), _ptr(dout), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
                                           _ptr(c1), _ptr(c2), _ptr(dx), p, cp, ctx.act, slope, None, int(ctx.train),

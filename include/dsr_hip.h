@@ -139,8 +139,9 @@ int dsr_pw_bn_act_fwd(int dtype, const void* y, const float* scale, const float*
 int dsr_pw_bn_act_bwd_reduce(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
                              const float* mean, const float* rstd, size_t P, int Cp, int blocks, int rpb, int act,
                              float slope, const float* prelu, float* partial, dsr_stream_t s);
-int dsr_pw_bn_bwd_finalize(const float* partial, int blocks, int C, int Cp, float count, float* dgamma, float* dbeta,
-                           float* dprelu, float* c1, float* c2, dsr_stream_t s);
+int dsr_pw_bn_bwd_finalize(const float* partial, int blocks, int C, int Cp, float count, const float* mean,
+                           const float* rstd, float* dgamma, float* dbeta, float* dprelu, float* c1, float* c2,
+                           dsr_stream_t s);
 int dsr_pw_bn_act_bwd_apply(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
                             const float* mean, const float* rstd, const float* c1, const float* c2, void* dy, size_t P,
                             int Cp, int act, float slope, const float* prelu, int train, dsr_stream_t s);
