@@ -161,6 +161,7 @@ struct Cin8Args {
   float slope;
   int tiles_y, tiles_x, ntiles;
   unsigned x_bytes;
+  int nt_store;        // output beyond the Infinity Cache: nontemporal stores (set by the launcher)
 };
 void dsr_launch_conv_cin8(Cin8Args& a, int N, int dtype, hipStream_t st);
 
