@@ -356,6 +356,20 @@ extern "C" int dsr_conv_dgrad(const dsr_conv_desc* d, const void* dy, const void
     sn.flip = 1;
     if (dsr_launch_conv_smalln(sn, d->N, d->dtype, s)) return dsr_launch_status("dsr_conv_dgrad(small-n)");
   }
+  if (!folded && dsr_dgrad_s2_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->H, d->W, r8(d->Cin), r8(d->Cout), d->N)) {
+    // 3x3 stride 2 (discriminator.py:29-35): all four output-parity classes from one staged dY tile, one launch
+    DgradS2Args q;
+    memset(&q, 0, sizeof(q));
+    q.dy = dy;
+    q.w = w_dgrad;
+    q.dx = dx;
+    q.H = d->H;
+    q.W = d->W;
+    q.CinP = r8(d->Cin);
+    q.CoutP = r8(d->Cout);
+    dsr_launch_dgrad_s2(q, d->N, d->dtype, s);
+    return dsr_launch_status("dsr_conv_dgrad(s2)");
+  }
   const int st = d->stride;
   for (int ph = 0; ph < st; ++ph)
     for (int pw = 0; pw < st; ++pw) {
@@ -538,6 +552,8 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
     if (is_c64(d)) return "conv_c64_kernel<1>";
     if (is_tail9(d)) return "conv_dgrad_toeplitz9_kernel";
     if (is_smalln_dgrad(d)) return "conv_smalln_kernel";
+    if (dsr_dgrad_s2_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->H, d->W, r8(d->Cin), r8(d->Cout), d->N))
+      return "conv_dgrad_s2_kernel";
     // input gradient on the gather kernel: grid = the input pixels (stride 1) or one output-parity class of them (stride 2)
     const long long Mg = (long long)d->N * ((d->H + d->stride - 1) / d->stride) * ((d->W + d->stride - 1) / d->stride);
     return gemm_name(r8(d->Cin), Mg, r8(d->Cout) % 64 == 0 && (d->pad_mode == DSR_PAD_ZERO || d->pad == 0), false);

@@ -165,6 +165,19 @@ struct Cin8Args {
 };
 void dsr_launch_conv_cin8(Cin8Args& a, int N, int dtype, hipStream_t st);
 
+// input gradient of a 3x3 stride-2 pad-1 convolution in one launch (conv_dgrad_s2.hip)
+struct DgradS2Args {
+  const void* dy;     // [N][H/2][W/2][CoutP]
+  const void* w;      // dgrad weight image [9][CinP][CoutP]
+  void* dx;           // [N][H][W][CinP]
+  int H, W, CinP, CoutP;
+  int OH, OW, M, ci_blocks, kblocks;      // filled by the launcher
+  unsigned dy_bytes, w_bytes;
+  FastDiv fd_ghw, fd_gw;
+};
+bool dsr_dgrad_s2_supported(int KH, int KW, int stride, int pad, int pad_mode, int H, int W, int CinP, int CoutP, int N);
+void dsr_launch_dgrad_s2(DgradS2Args& a, int N, int dtype, hipStream_t st);
+
 // fused backward of a first layer (conv_first_bwd.hip)
 struct FirstBwdArgs {
   const void* x;       // [N][H][W][8]

@@ -492,6 +492,8 @@ def test_conv_256x256_tile_equals_128x128(dev, op):
     bias = (torch.rand(cout, generator=g) - 0.5).to(dev)
     outs, stats = [], []
     old = os.environ.get("DSR_CONV_BIG")
+    old_s2 = os.environ.get("DSR_DGRAD_S2")
+    os.environ["DSR_DGRAD_S2"] = "0"       # this test is about the gather kernel's tiles: keep stride-2 dgrads on it
     try:
         for mode in ("0", "2"):
             os.environ["DSR_CONV_BIG"] = mode
@@ -515,10 +517,11 @@ def test_conv_256x256_tile_equals_128x128(dev, op):
                 outs.append(dx)
             assert ("256x256" in name) == (mode == "2"), (mode, name)
     finally:
-        if old is None:
-            os.environ.pop("DSR_CONV_BIG", None)
-        else:
-            os.environ["DSR_CONV_BIG"] = old
+        for k, v in (("DSR_CONV_BIG", old), ("DSR_DGRAD_S2", old_s2)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     torch.cuda.synchronize()
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0], outs[1])
@@ -527,3 +530,47 @@ def test_conv_256x256_tile_equals_128x128(dev, op):
         assert float((stats[0] - stats[1]).abs().max() / stats[0].abs().max()) < 1e-6
         ref = torch.stack([outs[0].float().double().sum((0, 1, 2)), (outs[0].float().double() ** 2).sum((0, 1, 2))])
         assert float((stats[1] - ref).abs().max() / ref.abs().max()) < 2e-3      # (y is the bf16-rounded accumulator)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 64, 96, 64, 64), (1, 50, 38, 128, 192), (3, 32, 32, 256, 64)])
+def test_conv_dgrad_s2_single_launch_equals_four_launches(dev, n, h, w, cin, cout):
+    """conv_dgrad_s2_kernel (3x3 stride 2 pad 1 input gradient, all four output-parity classes from one staged dY tile;
+    discriminator.py:29-35) against the four gather-kernel launches it replaces: same products in the same order, so BIT FOR
+    BIT equal, ragged M tail included; and against a float64 conv_transpose on the same bf16 operands."""
+    import ctypes as C
+    import os
+    L = P("_lib")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = L.ConvDesc(L.BF16, n, h, w, cin, cout, 3, 3, 2, 1, 0)
+    oh, ow = h // 2, w // 2
+    g = torch.Generator(device="cpu").manual_seed(11)
+    wt = bfr((torch.rand(cout, cin, 3, 3, generator=g) - 0.5) * 0.2)
+    wf = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 0), dtype=torch.bfloat16, device=dev)
+    wd = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 1), dtype=torch.bfloat16, device=dev)
+    wdev = wt.to(dev)
+    L.check(lib.dsr_conv_pack_weight(C.byref(d), wdev.data_ptr(), wf.data_ptr(), wd.data_ptr(), st))
+    dy = bfr(torch.rand(n, cout, oh, ow, generator=g) - 0.5)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)
+    outs = []
+    old = os.environ.get("DSR_DGRAD_S2")
+    try:
+        for mode in ("0", "2"):        # 0: four parity-class launches, 2: the single-launch kernel whatever the grid size
+            os.environ["DSR_DGRAD_S2"] = mode
+            dx = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
+            name = lib.dsr_conv_kernel_name(C.byref(d), 1, None).decode()
+            assert (name == "conv_dgrad_s2_kernel") == (mode == "2"), (mode, name)
+            L.check(lib.dsr_conv_dgrad(C.byref(d), dyd.data_ptr(), wd.data_ptr(), dx.data_ptr(), None, 0, st))
+            outs.append(dx)
+    finally:
+        if old is None:
+            os.environ.pop("DSR_DGRAD_S2", None)
+        else:
+            os.environ["DSR_DGRAD_S2"] = old
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[0], outs[1])
+    ref = TF.conv_transpose2d(dy.double(), wt.double(), stride=2, padding=1, output_padding=1)
+    got = outs[1].float().permute(0, 3, 1, 2).cpu().double()
+    assert tuple(ref.shape) == tuple(got.shape)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1.2e-2
