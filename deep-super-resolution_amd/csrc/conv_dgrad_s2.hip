@@ -50,34 +50,36 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;           // pixel half, 16-channel slice
   const int g = lane >> 4, r16 = lane & 15;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int cib = bid % a.ci_blocks, tile_m = bid / a.ci_blocks;
-  const int m0 = tile_m * S2_BM;
 
   // ---- loader role: 16-byte slot j of tile row rb + 64*i (A), of weight row rb (B)
   const int j = tid & 7, rb = tid >> 3;
   const int jc = j ^ (rb & 7);                       // source-side swizzle (the LDS image of a DMA is lane-linear)
-  int a_gy[4], a_gx[4], a_base[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + rb + 64 * i;
-    const bool ok = m < a.M;
-    const int mm = ok ? m : 0;
-    const int n = fd_div(a.fd_ghw, mm);
-    const int rem = mm - n * (a.OH * a.OW);
-    const int gy = fd_div(a.fd_gw, rem);
-    const int gx = rem - gy * a.OW;
-    a_gy[i] = ok ? gy : (1 << 20);                   // rows past M: every shift lands out of range
-    a_gx[i] = gx;
-    a_base[i] = (((n * a.OH + gy) * a.OW + gx) * a.CoutP + jc * 8) * 2;
-  }
-  const int b_base = ((cib * 64 + rb) * a.CoutP + jc * 8) * 2;        // + tap * CinP * CoutP * 2 + kb * 128
+  int a_gy[4], a_gx[4], a_base[4], b_base = 0;
   const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dxr = __builtin_amdgcn_make_buffer_rsrc(a.dx, 0, a.dx_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int tap_stride = a.CinP * a.CoutP * 2;
 
+  // the block's tile t = (pixel tile, 64-channel block of dx): loader addresses
+  auto setup = [&](int t) {
+    const int cib = t % a.ci_blocks, m0 = (t / a.ci_blocks) * S2_BM;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + rb + 64 * i;
+      const bool ok = m < a.M;
+      const int mm = ok ? m : 0;
+      const int n = fd_div(a.fd_ghw, mm);
+      const int rem = mm - n * (a.OH * a.OW);
+      const int gy = fd_div(a.fd_gw, rem);
+      const int gx = rem - gy * a.OW;
+      a_gy[i] = ok ? gy : (1 << 20);                 // rows past M: every shift lands out of range
+      a_gx[i] = gx;
+      a_base[i] = (((n * a.OH + gy) * a.OW + gx) * a.CoutP + jc * 8) * 2;
+    }
+    b_base = ((cib * 64 + rb) * a.CoutP + jc * 8) * 2;      // + tap * CinP * CoutP * 2 + kb * 128
+  };
   auto dma_issue = [&](int s, int kb, int stage) {
     const int sy = s >> 1, sx = s & 1;
     const int toff = ((sy * a.OW + sx) * a.CoutP + kb * 64) * 2;
@@ -97,87 +99,117 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
     }
   };
 
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   const int sw = r16 & 7;
   const bool late_dma = wave >= 4;
-  // Steps run shift-major in the order 3, 2, 1, 0 with the 64-channel blocks of dY innermost: inside every class that is
-  // the gather kernel's own order (taps ascending in kh,kw, channel blocks inside a tap), so the fp32 sums are identical.
-  // One barrier per step: {my DMA of this step has landed; barrier; start the next step's DMA into the other stage; MFMAs}.
-  // The shift loop is unrolled: the set of classes a step feeds is static.
-  int q = 0;
-  dma_issue(3, 0, 0);
+  const int ntiles = a.tiles_m * a.ci_blocks;
+  // Persistent: a block walks tiles t, t + gridDim.x, ...  The first DMA of tile t+1 is issued during the LAST step of tile
+  // t (into the stage that step is not reading), BEFORE tile t's 16 output stores per thread, so at the top of tile t+1
+  // "s_waitcnt vmcnt(16)" waits for that DMA only (vmcnt retires in order) and the stores -- 128 KB per tile, the dominant
+  // cost of the layers with few channels -- drain under the next tile's MFMAs.  Every thread issues exactly 16 stores
+  // (range-checked buffer stores: rows past M go to an out-of-range offset).
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  int q = 0;               // global step counter: stage = q & 1
+  bool first_tile = true;
+  if (t < ntiles) {
+    setup(t);
+    dma_issue(3, 0, 0);
+  }
+  for (; t < ntiles; t += gridDim.x) {
+    const int cib = t % a.ci_blocks, m0 = (t / a.ci_blocks) * S2_BM;     // (this tile's, for the stores)
+    const int tn = t + (int)gridDim.x;
+    f32x4 acc[8][4];
 #pragma unroll
-  for (int s = 3; s >= 0; --s) {
-    for (int kb = 0; kb < a.kblocks; ++kb, ++q) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const int cur = q & 1;
-      const unsigned char* pa = smem + cur * S2_STAGE + (wm * 128 + r16) * 128;
-      const unsigned char* pb = smem + cur * S2_STAGE + S2_A + (wn * 16 + r16) * 128;
-      const bool same = kb + 1 < a.kblocks;
-      const bool more = same || s > 0;
-      const int ns = same ? s : s - 1, nkb = same ? kb + 1 : 0;
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int slot = ((4 * kk + g) ^ sw) << 4;
-        U4 fb[4];
+      for (int c = 0; c < 4; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Steps run shift-major in the order 3, 2, 1, 0 with the 64-channel blocks of dY innermost: inside every class that is
+    // the gather kernel's own order (taps ascending in kh,kw, channel blocks inside a tap), so the fp32 sums are identical.
+    // One barrier per step: {my DMA of this step has landed; barrier; start the next step's DMA into the other stage; MFMAs}.
+    // The shift loop is unrolled: the set of classes a step feeds is static.
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (s2_tap(c, s) >= 0) fb[c] = *reinterpret_cast<const U4*>(pb + c * S2_BSLOT + slot);
-        if (kk == 0 && !late_dma && more) dma_issue(ns, nkb, cur ^ 1);
+    for (int s = 3; s >= 0; --s) {
+      for (int kb = 0; kb < a.kblocks; ++kb, ++q) {
+        if (s == 3 && kb == 0 && !first_tile)
+          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the previous tile's stores stay in flight
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int cur = q & 1;
+        const unsigned char* pa = smem + cur * S2_STAGE + (wm * 128 + r16) * 128;
+        const unsigned char* pb = smem + cur * S2_STAGE + S2_A + (wn * 16 + r16) * 128;
+        const bool same = kb + 1 < a.kblocks;
+        const bool last = !same && s == 0;                    // last step of this tile
+        auto issue_next = [&]() {
+          if (!last) {
+            dma_issue(same ? s : s - 1, same ? kb + 1 : 0, cur ^ 1);
+          } else if (tn < ntiles) {                           // (uniform) next tile's first step
+            setup(tn);
+            dma_issue(3, 0, cur ^ 1);
+          }
+        };
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const U4 fa = *reinterpret_cast<const U4*>(pa + i * 16 * 128 + slot);
+        for (int kk = 0; kk < 2; ++kk) {
+          const int slot = ((4 * kk + g) ^ sw) << 4;
+          U4 fb[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            if (s2_tap(c, s) >= 0) acc[i][c] = mfma16<DT>(fb[c], fa, acc[i][c]);
-        }
-        if (kk == 0) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (late_dma && more) dma_issue(ns, nkb, cur ^ 1);
-          __builtin_amdgcn_sched_barrier(0);
+            if (s2_tap(c, s) >= 0) fb[c] = *reinterpret_cast<const U4*>(pb + c * S2_BSLOT + slot);
+          if (kk == 0 && !late_dma) issue_next();
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const U4 fa = *reinterpret_cast<const U4*>(pa + i * 16 * 128 + slot);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (s2_tap(c, s) >= 0) acc[i][c] = mfma16<DT>(fb[c], fa, acc[i][c]);
+          }
+          if (kk == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (late_dma) issue_next();
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
     }
-  }
-  __syncthreads();      // the stages become the C tile
-
-  // ---- epilogue: class by class, 256 pixels x 64 channels through LDS, then full 128-byte lines to dx
-  unsigned short* __restrict__ DX = reinterpret_cast<unsigned short*>(a.dx);
-  unsigned char* sC = smem;
+    first_tile = false;
+    // ---- epilogue: class by class, 256 pixels x 64 channels through LDS (the stage the last step read: the other one is
+    // receiving the next tile), then full 128-byte lines to dx.  Raw barriers: a __syncthreads() would drain the DMA.
+    unsigned char* sC = smem + ((q - 1) & 1) * S2_STAGE;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // every wave is done reading that stage
+    asm volatile("" ::: "memory");
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int ph = c >> 1, pw = c & 1;
+    for (int c = 0; c < 4; ++c) {
+      const int ph = c >> 1, pw = c & 1;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = wm * 128 + 16 * i + r16;
-      uint2 h;
-      h.x = (unsigned)f2h<DT>(acc[i][c][0]) | ((unsigned)f2h<DT>(acc[i][c][1]) << 16);
-      h.y = (unsigned)f2h<DT>(acc[i][c][2]) | ((unsigned)f2h<DT>(acc[i][c][3]) << 16);
-      *reinterpret_cast<uint2*>(sC + row * S2_CSTRIDE + (wn * 16 + 4 * g) * 2) = h;
-    }
-    __syncthreads();
+      for (int i = 0; i < 8; ++i) {
+        const int row = wm * 128 + 16 * i + r16;
+        uint2 h;
+        h.x = (unsigned)f2h<DT>(acc[i][c][0]) | ((unsigned)f2h<DT>(acc[i][c][1]) << 16);
+        h.y = (unsigned)f2h<DT>(acc[i][c][2]) | ((unsigned)f2h<DT>(acc[i][c][3]) << 16);
+        *reinterpret_cast<uint2*>(sC + row * S2_CSTRIDE + (wn * 16 + 4 * g) * 2) = h;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = tid + 512 * it;                // 256 rows x 8 chunks
-      const int row = idx >> 3, ch = idx & 7;
-      const int m = m0 + row;
-      if (m < a.M) {
-        const int n = fd_div(a.fd_ghw, m);
-        const int rem = m - n * (a.OH * a.OW);
+      for (int it = 0; it < 4; ++it) {
+        const int idx = tid + 512 * it;              // 256 rows x 8 chunks
+        const int row = idx >> 3, ch = idx & 7;
+        const int m = m0 + row;
+        const int mm = m < a.M ? m : 0;
+        const int n = fd_div(a.fd_ghw, mm);
+        const int rem = mm - n * (a.OH * a.OW);
         const int gy = fd_div(a.fd_gw, rem);
         const int gx = rem - gy * a.OW;
-        const size_t off = ((size_t)(n * a.H + 2 * gy + ph) * a.W + 2 * gx + pw) * a.CinP + cib * 64 + ch * 8;
-        *reinterpret_cast<U4*>(DX + off) = *reinterpret_cast<const U4*>(sC + row * S2_CSTRIDE + ch * 16);
+        const unsigned off = (unsigned)((((n * a.H + 2 * gy + ph) * a.W + 2 * gx + pw) * a.CinP + cib * 64 + ch * 8) * 2);
+        const U4 v = *reinterpret_cast<const U4*>(sC + row * S2_CSTRIDE + ch * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, dxr, m < a.M ? off : OOB, 0, 0);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                           // the C tile has been read: the next class may overwrite it
+      asm volatile("" ::: "memory");
     }
-    __syncthreads();
   }
 }
 
@@ -202,7 +234,10 @@ void dsr_launch_dgrad_s2(DgradS2Args& a, int N, int dtype, hipStream_t st) {
   a.w_bytes = (unsigned)((size_t)9 * a.CinP * a.CoutP * 2);
   a.fd_ghw = fd_make((unsigned)(a.OH * a.OW));
   a.fd_gw = fd_make((unsigned)a.OW);
-  const int blocks = ((a.M + S2_BM - 1) / S2_BM) * a.ci_blocks;
+  a.tiles_m = (a.M + S2_BM - 1) / S2_BM;
+  a.dx_bytes = (unsigned)((size_t)N * a.H * a.W * a.CinP * 2);
+  const int ntiles = a.tiles_m * a.ci_blocks;
+  const int blocks = ntiles < 256 ? ntiles : 256;          // persistent: one 8-wave block per CU (128 KB of LDS each)
   static bool attr_done = false;
   if (!attr_done) {       // more than 64 KB of dynamic LDS needs the opt-in, once per kernel (not a stream operation)
     (void)hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS);

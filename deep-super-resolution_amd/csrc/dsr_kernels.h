@@ -171,8 +171,8 @@ struct DgradS2Args {
   const void* w;      // dgrad weight image [9][CinP][CoutP]
   void* dx;           // [N][H][W][CinP]
   int H, W, CinP, CoutP;
-  int OH, OW, M, ci_blocks, kblocks;      // filled by the launcher
-  unsigned dy_bytes, w_bytes;
+  int OH, OW, M, ci_blocks, kblocks, tiles_m;      // filled by the launcher
+  unsigned dy_bytes, w_bytes, dx_bytes;
   FastDiv fd_ghw, fd_gw;
 };
 bool dsr_dgrad_s2_supported(int KH, int KW, int stride, int pad, int pad_mode, int H, int W, int CinP, int CoutP, int N);

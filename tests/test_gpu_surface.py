@@ -1,6 +1,7 @@
 """GPU: the rows next to the hot path -- activation-slope guards, differentiable loss targets, the LBFGS branch of
 utils/DIP.optimize over the HIP closure, a caller-supplied VGG state_dict, reference-format checkpoints through the
 mirror with the golden eval output, and the evaluation loop (PSNR, tiles, PNG)."""
+import contextlib
 import importlib
 import math
 import os
@@ -205,36 +206,54 @@ def test_optimize_lbfgs_over_hip_closure(dev):
     U.optimize("LBFGS", U.get_params("net", net, zd), closure, 0.01, num_iter)
     torch.cuda.synchronize()
     hip = [float(v) for v in hist]
-    # --- oracle: the reference's own branch text, on the fp32 restatement
-    osd = {k: v.clone() for k, v in sd.items()}
-    params = recipes.leaves(osd)
-    ref = []
+    # --- oracle: the reference's own branch text, on the fp32 restatement -- and once more with bf16 conv storage
+    # (oracle/lowp.py), which measures how far 16-bit storage alone moves this trajectory
+    def reference_run(storage):
+        osd = {k: v.clone() for k, v in sd.items()}
+        params = recipes.leaves(osd)
+        ref = []
 
-    def rclosure():
-        out = dip.skip_forward(osd, zin, cfg, True)
-        loss = losses.mse(downsampler.downsampler_forward(out, 2, "lanczos2", phase=0.5, preserve_size=True), lr_img)
-        loss.backward()
-        ref.append(float(loss.detach()))
-        return loss
+        def rclosure():
+            out = dip.skip_forward(osd, zin, cfg, True)
+            loss = losses.mse(downsampler.downsampler_forward(out, 2, "lanczos2", phase=0.5, preserve_size=True), lr_img)
+            loss.backward()
+            ref.append(float(loss.detach()))
+            return loss
 
-    opt = torch.optim.Adam(params, lr=0.001)
-    for _ in range(100):
-        opt.zero_grad()
-        rclosure()
-        opt.step()
-    opt = torch.optim.LBFGS(params, max_iter=num_iter, lr=0.01, tolerance_grad=-1, tolerance_change=-1)
+        with storage:
+            opt = torch.optim.Adam(params, lr=0.001)
+            for _ in range(100):
+                opt.zero_grad()
+                rclosure()
+                opt.step()
+            opt = torch.optim.LBFGS(params, max_iter=num_iter, lr=0.01, tolerance_grad=-1, tolerance_change=-1)
 
-    def rclosure2():
-        opt.zero_grad()
-        return rclosure()
+            def rclosure2():
+                opt.zero_grad()
+                return rclosure()
 
-    opt.step(rclosure2)
+            opt.step(rclosure2)
+        return ref
+
+    ref = reference_run(contextlib.nullcontext())
+    low = reference_run(lowp.storage(torch.bfloat16))
     assert len(hip) == len(ref) >= 100 + num_iter               # same number of closure evaluations
     assert abs(hip[0] - ref[0]) < 0.02 * ref[0]
-    # 100 Adam steps on a 3-scale net that normalises 4x4 maps at batch 1: bf16 storage moves the loss by ~10 % by then
-    assert abs(hip[99] - ref[99]) < 0.15 * ref[99], (hip[99], ref[99])          # end of the Adam warm-up
-    assert hip[-1] < hip[99] * 1.001 and ref[-1] < ref[99] * 1.001             # LBFGS kept descending on both sides
-    assert abs(hip[-1] - ref[-1]) < 0.2 * ref[-1], (hip[-1], ref[-1])
+    # (Adam's first updates are lr * sign(g) per element: a rounding-level change of a near-zero gradient moves a parameter by
+    # 2 lr, so the second loss already differs by ~5 % -- as the bf16-storage oracle's does at step 2)
+    for i in (1, 2, 5, 10):
+        assert abs(hip[i] - ref[i]) < 2.5 * abs(low[i] - ref[i]) + 0.08 * ref[i], (i, hip[i], ref[i], low[i])
+    # 100 Adam steps on a 3-scale net that normalises 4x4 maps at batch 1 amplify storage rounding erratically (the
+    # bf16-storage oracle is 6 % off the fp32 one at step 2, 1.5 % at step 10, 8 % at step 99; two CPUs disagree on the fp32
+    # loss at step 99 by 0.4 %), so late losses are compared as means over the last ten Adam steps / the LBFGS phase, and the
+    # bar is the measured floor: the HIP mean may sit 2.5x as far from the fp32 oracle as the bf16-storage oracle does, + 5 %
+    def window(v, lo, hi):
+        return sum(v[lo:hi]) / (hi - lo)
+
+    for lo, hi in ((90, 100), (100, len(ref))):
+        h, r, f = window(hip, lo, hi), window(ref, lo, hi), window(low, lo, hi)
+        assert abs(h - r) < 2.5 * abs(f - r) + 0.05 * r, (lo, hi, h, r, f)
+    assert hip[-1] < hip[99] * 1.001 and ref[-1] < ref[99] * 1.001               # LBFGS kept descending on both sides
 
 
 # ----------------------------------------------------------------------------- f2: checkpoints + eval loop

@@ -30,9 +30,13 @@ SHAPES = [  # name, N, H, W, Cin, Cout, k, stride, pad
     ("D.b4 256->256 s2 @128", 32, 128, 128, 256, 256, 3, 2, 1),
     ("D.b5 256->512 @64", 32, 64, 64, 256, 512, 3, 1, 1),
     ("D.b6 512->512 s2 @64", 32, 64, 64, 512, 512, 3, 2, 1),
+    ("V.3->64 @224", 32, 224, 224, 3, 64, 3, 1, 1),
     ("V.64->64 @224", 32, 224, 224, 64, 64, 3, 1, 1),
+    ("V.64->128 @112", 32, 112, 112, 64, 128, 3, 1, 1),
     ("V.128->128 @112", 32, 112, 112, 128, 128, 3, 1, 1),
+    ("V.128->256 @56", 32, 56, 56, 128, 256, 3, 1, 1),
     ("V.256->256 @56", 32, 56, 56, 256, 256, 3, 1, 1),
+    ("V.256->512 @28", 32, 28, 28, 256, 512, 3, 1, 1),
     ("V.512->512 @28", 32, 28, 28, 512, 512, 3, 1, 1),
     ("V.512->512 @14", 32, 14, 14, 512, 512, 3, 1, 1),
 ]
@@ -86,8 +90,10 @@ def main():
         wsz2 = lib.dsr_conv_wgrad_workspace(C.byref(d))
         ws2 = torch.empty(wsz2, dtype=torch.uint8, device=dev)
         tw = timeit(lambda: L.check(lib.dsr_conv_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws2.data_ptr(), wsz2, st)))
-        print(f"{name:28s} {fl/1e9:8.1f} | {tf*1e3:8.3f} {fl/tf/1e12:6.0f} | {td*1e3:8.3f} {fl/td/1e12:6.0f} | {tw*1e3:8.3f} {fl/tw/1e12:6.0f}",
-              flush=True)
+        names = [lib.dsr_conv_kernel_name(C.byref(d), op, C.byref(ep) if op == 0 else None).decode().replace("conv_", "").replace("_kernel", "")
+                 for op in (0, 1, 2)]
+        print(f"{name:28s} {fl/1e9:8.1f} | {tf*1e3:8.3f} {fl/tf/1e12:6.0f} | {td*1e3:8.3f} {fl/td/1e12:6.0f} | {tw*1e3:8.3f} {fl/tw/1e12:6.0f}"
+              f" | {' / '.join(names)}", flush=True)
 
 
 if __name__ == "__main__":
