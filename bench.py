@@ -144,7 +144,9 @@ def build_step(workload, dev, world):
     perc = GANu.PerceptualLoss().to(dev)
     D.broadcast_module(gen)
     D.broadcast_module(disc)
-    opt_d = optim.FusedAdam(disc.parameters(), lr=1e-4)
+    # dense1's 2.1 GB gradient stays in factored form and Adam is applied inside its contraction (same arithmetic bit for bit,
+    # tests/test_gpu_models.py::test_fused_dense_adam_equals_separate_launches); DSR_FUSE_DENSE_ADAM=0: two launches
+    opt_d = optim.FusedAdam(disc.parameters(), lr=1e-4, fuse_dense_head=os.environ.get("DSR_FUSE_DENSE_ADAM", "1") != "0")
     sync_d = D.GradSync(disc.parameters()).attach()
     overlap = os.environ.get("DSR_GAN_OVERLAP", "1") != "0"
 

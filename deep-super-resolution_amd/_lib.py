@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libdsr_hip.so")
 
-ABI_VERSION = 4          # bumped whenever a signature in include/dsr_hip.h changes; checked against the loaded library
+ABI_VERSION = 5          # bumped whenever a signature in include/dsr_hip.h changes; checked against the loaded library
 BF16, F16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_PRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_ELU = range(7)
 PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = range(3)
@@ -79,6 +79,7 @@ SIGNATURES = {
     "dsr_linear_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _Z, _P]),
     "dsr_linear_wgrad": (_I, [_I, _P, _P, _P, _I, _I, _Z, _P]),
     "dsr_linear_wgrad_gathered": (_I, [_I, _P, _P, _P, _I, _I, _Z, _I, _F, _P]),
+    "dsr_linear_wgrad_adam": (_I, [_I, _P, _P, _I, _I, _Z, _I, _F, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _P]),
     "dsr_dense2_fwd": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "dsr_dense2_bwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "dsr_maxpool2_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),

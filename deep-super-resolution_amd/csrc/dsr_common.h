@@ -148,6 +148,33 @@ __device__ __forceinline__ f32x16 mfma32(const U4& a, const U4& b, f32x16 c) {
   }
 }
 
+// Adam (torch.optim.Adam defaults, no weight decay): ONE statement of the arithmetic, used by every kernel that applies it
+// (pointwise.hip adam_kernel / adam_multi_kernel, linear.hip linear_wgrad_adam_kernel), with floating-point contraction
+// off so that each of them rounds identically -- the fused weight-gradient + Adam launch is tested bit-for-bit against
+// the two separate launches.
+struct AdamCoef {
+  float step_size, rbc2, b1, b2, eps, grad_scale;
+};
+__device__ __forceinline__ AdamCoef adam_coef(const int* __restrict__ step, float lr, float b1, float b2, float eps,
+                                              float grad_scale) {
+  const int t = *step;
+  AdamCoef c;
+  c.step_size = lr / (1.f - powf(b1, (float)t));
+  c.rbc2 = 1.f / sqrtf(1.f - powf(b2, (float)t));
+  c.b1 = b1;
+  c.b2 = b2;
+  c.eps = eps;
+  c.grad_scale = grad_scale;
+  return c;
+}
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, const AdamCoef& c) {
+#pragma clang fp contract(off)
+  const float gk = g * c.grad_scale;          // 1/S un-does a static loss scale (fp16 storage); 1 otherwise
+  m = c.b1 * m + (1.f - c.b1) * gk;
+  v = c.b2 * v + (1.f - c.b2) * gk * gk;
+  p -= c.step_size * (m / (sqrtf(v) * c.rbc2 + c.eps));
+}
+
 // XCD-aware, bijective block-id remap (consecutive logical tiles share an XCD's L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int nx = 8;

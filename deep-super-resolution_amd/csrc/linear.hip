@@ -9,6 +9,8 @@
 //   linear_dgrad : dx[b][k] = sum_o dy[b][o] W[o][k]  -- W tile through LDS, ds_read_b64_tr_b16 transposes
 //   linear_wgrad : dW[o][k] = sum_b dy[b][o] x[b][k]  -- batch is the MFMA K; 16-byte fp32 stores
 #include "../../include/dsr_hip.h"
+#include <cstdlib>
+
 #include "dsr_common.h"
 #include "dsr_kernels.h"
 
@@ -327,6 +329,123 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const unsigned short*
   }
 }
 
+// ------------------------------------------------------------------ wgrad + Adam in one pass
+// dense1 of the config-3 discriminator holds 537 M parameters: its gradient is a rank-64 product (64 samples), so
+// "write 2.1 GB of dW, then read it back in the Adam launch" is 4.3 GB of HBM traffic for a tensor that never needs to
+// exist.  Here a wave forms a 64 (o) x 64 (k) tile of dW in MFMA accumulators exactly as linear_wgrad_kernel /
+// linear_wgrad_gathered_kernel do (same fragments, same order: the same bits), turns it through LDS so that a lane owns
+// 4 consecutive k of one row, and applies Adam to p / m / v in place (16-byte nontemporal accesses, full 128-byte lines
+// per row for the fp32 tensors AND for the bf16 shadow of p, which is why the tile is 64 k wide).
+struct AdamFused {
+  float* p;
+  float* m;
+  float* v;
+  unsigned short* shadow;   // bf16 image of p (the MFMA operand of the next forward), may be null
+  const int* step;
+  float lr, b1, b2, eps, grad_scale;
+};
+template <int DT, int BP>
+__global__ __launch_bounds__(256, 2) void linear_wgrad_adam_kernel(const unsigned short* __restrict__ dyT,
+                                                                   const unsigned short* __restrict__ xT, int O, size_t K,
+                                                                   int R, float scale, int kpairs_per_block,
+                                                                   const AdamFused a) {
+  typedef __attribute__((ext_vector_type(4))) float F4;
+  typedef __attribute__((ext_vector_type(2))) unsigned U2;
+  constexpr int RS = 72;                         // tile row pitch in floats: 4 * RS = 32 (mod 64 banks), so the two half-waves
+                                                 // of a ds_write_b32 (rows 4 apart) land on disjoint banks
+  __shared__ __attribute__((aligned(16))) float tile[4][32 * RS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hf = lane >> 5;
+  // the four waves of a block share 64 rows of o and take adjacent 64-wide k tiles: the block touches 1 KB contiguous
+  // per row and tensor at a time (rows are K * 4 bytes = 2 MB apart)
+  const int o0 = blockIdx.y * 64;
+  constexpr int KS = BP / 16;
+  const AdamCoef co = adam_coef(a.step, a.lr, a.b1, a.b2, a.eps, a.grad_scale);
+  float* my = tile[wave];                        // (no block-level barrier below: a wave owns its slice of `tile`)
+  const size_t kp0 = (size_t)blockIdx.x * kpairs_per_block;
+  for (int t = 0; t < kpairs_per_block; ++t) {
+    const size_t kbase = ((kp0 + t) * 4 + wave) * 64;
+    if (kbase >= K) break;
+    f32x16 acc[2][2];                            // [mf: 32-row half of the wave's 64 o][kt: 32-wide half of the 64 k]
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mf][kt][i] = 0.f;
+    for (int q = 0; q < R; ++q) {
+      U4 fa[2][KS], fb[2][KS];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const size_t krow = kbase + 32 * kt + r;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) fb[kt][s] = load16_or_zero(xT, ((size_t)q * K + krow) * BP + 16 * s + 8 * hf, krow < K);
+      }
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) {
+        const int o = o0 + 32 * mf + r;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) fa[mf][s] = load16_or_zero(dyT, ((size_t)q * O + o) * BP + 16 * s + 8 * hf, o < O);
+      }
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int s = 0; s < KS; ++s) acc[mf][kt] = mfma32<DT>(fa[mf][s], fb[kt][s], acc[mf][kt]);
+    }
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      // this lane's part of the 32 x 64 tile after the turn: rows 4 j + (lane >> 4), floats 4 (lane & 15) .. + 3
+      const int rr = lane >> 4, kc = 4 * (lane & 15);
+      F4 pv[8], mv[8], vv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {              // requested before the turn: 24 x 16 bytes per lane in flight
+        const int o = o0 + 32 * mf + 4 * j + rr;
+        const size_t e = (size_t)(o < O ? o : 0) * K + kbase + kc;
+        pv[j] = __builtin_nontemporal_load(reinterpret_cast<const F4*>(a.p + e));
+        mv[j] = __builtin_nontemporal_load(reinterpret_cast<const F4*>(a.m + e));
+        vv[j] = __builtin_nontemporal_load(reinterpret_cast<const F4*>(a.v + e));
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          my[(8 * (i >> 2) + 4 * hf + (i & 3)) * RS + 32 * kt + r] = acc[mf][kt][i] * scale;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();           // (LDS serves one wave's requests in order; this only pins the compiler)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int o = o0 + 32 * mf + 4 * j + rr;
+        const F4 g = *reinterpret_cast<const F4*>(my + (4 * j + rr) * RS + kc);
+        F4 pn = pv[j], mn = mv[j], vn = vv[j];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float pk = pn[c], mk = mn[c], vk = vn[c];
+          adam_update(pk, g[c], mk, vk, co);
+          pn[c] = pk;
+          mn[c] = mk;
+          vn[c] = vk;
+        }
+        if (o < O) {
+          const size_t e = (size_t)o * K + kbase + kc;
+          __builtin_nontemporal_store(pn, reinterpret_cast<F4*>(a.p + e));
+          __builtin_nontemporal_store(mn, reinterpret_cast<F4*>(a.m + e));
+          __builtin_nontemporal_store(vn, reinterpret_cast<F4*>(a.v + e));
+          if (a.shadow) {
+            U2 h;
+            h.x = (unsigned)f2h<DSR_DTYPE_BF16>(pn[0]) | ((unsigned)f2h<DSR_DTYPE_BF16>(pn[1]) << 16);
+            h.y = (unsigned)f2h<DSR_DTYPE_BF16>(pn[2]) | ((unsigned)f2h<DSR_DTYPE_BF16>(pn[3]) << 16);
+            __builtin_nontemporal_store(h, reinterpret_cast<U2*>(a.shadow + e));
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();           // the tile is free again
+    }
+  }
+}
+
 // Data-parallel form: dW = scale * sum_r dyT_r xT_r over R gathered rank-local factor pairs ([R][O][BP], [R][K][BP]).
 // A data-parallel step would otherwise all-reduce dW itself (2.1 GB for the config-3 dense1; one xGMI link between two
 // GPUs moves that in ~30 ms) while the factors are 67 MB + 128 KB per rank: all-gather those and form the summed
@@ -558,6 +677,43 @@ extern "C" int dsr_linear_wgrad_gathered(int dtype, const void* dyT16_all, const
   }
 #undef LAUNCH_WGG
   return dsr_launch_status("dsr_linear_wgrad_gathered");
+}
+
+extern "C" int dsr_linear_wgrad_adam(int dtype, const void* dyT16_all, const void* xT16_all, int Bp, int O, size_t K, int R,
+                                     float scale, float* p, float* m, float* v, void* shadow_bf16, const int* step, float lr,
+                                     float b1, float b2, float eps, float grad_scale, dsr_stream_t st) {
+  DSR_REQUIRE(dyT16_all && xT16_all && p && m && v && step && DSR_DTYPE_OK(dtype) && K > 0 && O > 0,
+              "linear_wgrad_adam: null pointer or bad shape");
+  if (Bp != 32 && Bp != 64) return dsr_fail(DSR_E_UNSUPPORTED, "linear_wgrad_adam: padded batch must be 32 or 64");
+  if (R < 1) return dsr_fail(DSR_E_ARG, "linear_wgrad_adam: R < 1");
+  if (K % 64) return dsr_fail(DSR_E_UNSUPPORTED, "linear_wgrad_adam: K %% 64 (use dsr_linear_wgrad + dsr_pw_adam)");
+  const char* e = getenv("DSR_WGRAD_ADAM_KPB");      // tuning switch: 256-wide k groups per block
+  const int kpb = e ? atoi(e) : 2;
+  if (kpb < 1) return dsr_fail(DSR_E_ARG, "linear_wgrad_adam: DSR_WGRAD_ADAM_KPB < 1");
+  const size_t kgroups = (K + 255) / 256;
+  dim3 grid((unsigned)((kgroups + kpb - 1) / kpb), (O + 63) / 64), block(256);
+  const unsigned short* DYT = (const unsigned short*)dyT16_all;
+  const unsigned short* XT = (const unsigned short*)xT16_all;
+  AdamFused a;
+  a.p = p;
+  a.m = m;
+  a.v = v;
+  a.shadow = (unsigned short*)shadow_bf16;
+  a.step = step;
+  a.lr = lr;
+  a.b1 = b1;
+  a.b2 = b2;
+  a.eps = eps;
+  a.grad_scale = grad_scale;
+#define LAUNCH_WGA(DTV, BPV) \
+  hipLaunchKernelGGL((linear_wgrad_adam_kernel<DTV, BPV>), grid, block, 0, st, DYT, XT, O, K, R, scale, kpb, a)
+  if (dtype == DSR_BF16) {
+    if (Bp == 32) LAUNCH_WGA(DSR_DTYPE_BF16, 32); else LAUNCH_WGA(DSR_DTYPE_BF16, 64);
+  } else {
+    if (Bp == 32) LAUNCH_WGA(DSR_DTYPE_F16, 32); else LAUNCH_WGA(DSR_DTYPE_F16, 64);
+  }
+#undef LAUNCH_WGA
+  return dsr_launch_status("dsr_linear_wgrad_adam");
 }
 
 extern "C" int dsr_dense2_fwd(const float* h, const float* w2, const float* b2, int B, int K1, float* out,

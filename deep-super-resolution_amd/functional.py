@@ -682,6 +682,7 @@ class DenseHead(torch.autograd.Function):
         check(lib.dsr_dense2_fwd(_ptr(h1), _ptr(w2), _ptr(b2), n, o, _ptr(out), st))
         ctx.c = c
         ctx.dp_world = dp_world_for(w1)
+        ctx.w1 = w1                     # (the Parameter itself: backward may hand its gradient over in factored form)
         ctx.save_for_backward(x, h1, out, w16, w2)
         return out
 
@@ -719,16 +720,48 @@ class DenseHead(torch.autograd.Function):
             dx = torch.empty_like(x)
             check(lib.dsr_flatten(_dt(x), _ptr(dflat), _ptr(dx), n, hw, c, cp, 0, 2, st))
         if ctx.needs_input_grad[1]:
-            dw1 = torch.empty((o, k), dtype=torch.float32, device=dev)
+            works = ()
             if gather is not None:
-                xt_all, dyt_all, works = gather
-                for wk in works:
-                    wk.wait()
-                check(lib.dsr_linear_wgrad_gathered(_dt(x), _ptr(dyt_all), _ptr(xt_all), _ptr(dw1), bp, o, k, ctx.dp_world,
-                                                    1.0 / ctx.dp_world, st))
+                xt, dyt16, works = gather
+            ranks = max(ctx.dp_world, 1) if gather is not None else 1
+            fac = GradFactors(_dt(x), dyt16, xt, bp, o, k, ranks, 1.0 / ranks, works)
+            if getattr(ctx.w1, "_dsr_defer_wgrad", False) and k % 64 == 0:
+                # optim.FusedAdam(fuse_dense_head=True): dW1 = dyT x is a rank-(64 R) product -- hand the two factors to
+                # the optimiser, whose dsr_linear_wgrad_adam launch forms each tile of it in registers and applies Adam
+                # there; the 2.1 GB gradient (config 3) is neither written nor read back
+                pending = getattr(ctx.w1, "_dsr_grad_factors", None)
+                if pending is None:
+                    pending = ctx.w1._dsr_grad_factors = []
+                pending.append(fac)
             else:
-                check(lib.dsr_linear_wgrad(_dt(x), _ptr(dyt16), _ptr(xt), _ptr(dw1), bp, o, k, st))
+                dw1 = fac.materialize()
         return dx, dw1, db1, dw2, db2, None
+
+
+class GradFactors:
+    """The gradient of a Linear weight as its two 16-bit factors: dW[o][k] = scale * sum_r sum_b dyT[r][o][b] xT[r][k][b]
+    (R rank-local pairs, all-gathered under data parallelism -- `works` are the pending gathers)."""
+
+    def __init__(self, dt, dyt, xt, bp, o, k, ranks, scale, works):
+        self.dt, self.dyt, self.xt, self.bp, self.o, self.k = dt, dyt, xt, bp, o, k
+        self.ranks, self.scale, self.works = ranks, scale, tuple(works)
+
+    def wait(self):
+        for wk in self.works:
+            wk.wait()
+        self.works = ()
+
+    def materialize(self):
+        """The fp32 [o][k] gradient (what Tensor.grad would have held)."""
+        lib = _lib.lib()
+        self.wait()
+        dw = torch.empty((self.o, self.k), dtype=torch.float32, device=self.xt.device)
+        if self.ranks > 1 or self.scale != 1.0:
+            check(lib.dsr_linear_wgrad_gathered(self.dt, _ptr(self.dyt), _ptr(self.xt), _ptr(dw), self.bp, self.o, self.k,
+                                                self.ranks, self.scale, _stream()))
+        else:
+            check(lib.dsr_linear_wgrad(self.dt, _ptr(self.dyt), _ptr(self.xt), _ptr(dw), self.bp, self.o, self.k, _stream()))
+        return dw
 
 
 # ----------------------------------------------------------------------------- pooling / resampling

@@ -12,10 +12,19 @@ from .functional import _ptr, _stream, bump, check, mark_shadow_current, repack_
 class FusedAdam:
     MULTI_MAX = 1 << 20      # tensors up to this many elements go through the multi-tensor launch
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, fuse_dense_head=False):
         self.params = [p for p in params]
         if not self.params:
             raise ValueError("optimizer got an empty parameter list")   # torch.optim raises the same
+        # fuse_dense_head: the dense head's big matrix (discriminator.py:54, marked `_dsr_dense_head`) gets its gradient as
+        # two 16-bit factors (functional.GradFactors) instead of a `.grad` tensor, and step() applies Adam inside the
+        # weight-gradient contraction (dsr_linear_wgrad_adam).  Same arithmetic, bit for bit; `.grad` of that one tensor
+        # stays None, which is why it is opt-in (steps / bench turn it on, nothing else reads that gradient).
+        self.fuse_dense_head = bool(fuse_dense_head)
+        if self.fuse_dense_head:
+            for p in self.params:
+                if getattr(p, "_dsr_dense_head", False):
+                    p._dsr_defer_wgrad = True
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
         self.grad_scale = float(grad_scale)     # gradients are multiplied by this first (1/S for a loss scale S)
         dev = self.params[0].device
@@ -25,6 +34,8 @@ class FusedAdam:
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
+            if getattr(p, "_dsr_grad_factors", None):
+                p._dsr_grad_factors = []
             if set_to_none:
                 p.grad = None
             elif p.grad is not None:
@@ -36,6 +47,24 @@ class FusedAdam:
         check(lib.dsr_pw_incr(_ptr(self.step_t), st))
         small, keep = [], []
         for p, m, v in zip(self.params, self.m, self.v):
+            pending = getattr(p, "_dsr_grad_factors", None)
+            if pending:
+                p._dsr_grad_factors = []
+                if len(pending) == 1 and p.grad is None and p.is_contiguous():
+                    f = pending[0]
+                    f.wait()
+                    sh = shadow_for_update(p)
+                    check(lib.dsr_linear_wgrad_adam(f.dt, _ptr(f.dyt), _ptr(f.xt), f.bp, f.o, f.k, f.ranks, f.scale, _ptr(p),
+                                                    _ptr(m), _ptr(v), _ptr(sh), _ptr(self.step_t), self.lr, self.betas[0],
+                                                    self.betas[1], self.eps, self.grad_scale, st))
+                    bump(p)
+                    if sh is not None:
+                        mark_shadow_current(p)
+                    continue
+                # several backward passes since zero_grad (or a .grad from elsewhere): accumulate like autograd would
+                for f in pending:
+                    g = f.materialize()
+                    p.grad = g if p.grad is None else p.grad + g
             if p.grad is None:
                 continue
             g = p.grad

@@ -189,6 +189,13 @@ int dsr_linear_wgrad(int dtype, const void* dyT16, const void* xT16, float* dw, 
  * (all-gather the 67 MB + 128 KB factors instead of all-reducing the 2.1 GB gradient) */
 int dsr_linear_wgrad_gathered(int dtype, const void* dyT16_all, const void* xT16_all, float* dw, int Bp, int O, size_t K,
                               int R, float scale, dsr_stream_t s);
+/* the same contraction with torch.optim.Adam's update applied to p / m / v (and p's bf16 shadow) in the epilogue: the
+ * gradient is never written (R = 1, scale = 1: bit-identical to dsr_linear_wgrad followed by dsr_pw_adam); K % 64 == 0.
+ * Replaces loss.backward() writing dense1.weight.grad + optimizer.step() reading it (train_GAN.py:52-53 on
+ * discriminator.py:54). */
+int dsr_linear_wgrad_adam(int dtype, const void* dyT16_all, const void* xT16_all, int Bp, int O, size_t K, int R, float scale,
+                          float* p, float* m, float* v, void* shadow_bf16, const int* step, float lr, float b1, float b2,
+                          float eps, float grad_scale, dsr_stream_t s);
 /* out[b] = sigmoid(h[b][:] . w2 + b2) */
 int dsr_dense2_fwd(const float* h, const float* w2, const float* b2, int B, int K1, float* out, dsr_stream_t s);
 /* backward of the fp32 tail; also emits the 16-bit dy / dy^T operands of the two dense1 GEMMs */

@@ -42,7 +42,7 @@ def test_ctypes_signatures_match_header(so):
     for name, (_, args) in L.SIGNATURES.items():
         assert len(args) == decl[name], (name, len(args), decl[name])
     L.lib()
-    assert L.lib().dsr_abi_version() == L.ABI_VERSION == 4
+    assert L.lib().dsr_abi_version() == L.ABI_VERSION == 5
 
 
 def test_host_side_descriptor_checks(so):
@@ -120,6 +120,8 @@ def test_bad_arguments_return_codes_not_crashes(so):
         lambda: lib.dsr_linear_dgrad(0, N, N, N, 4, 8, 64, st),
         lambda: lib.dsr_linear_wgrad(0, N, N, N, 32, 8, 64, st),
         lambda: lib.dsr_linear_wgrad_gathered(0, N, N, N, 32, 8, 64, 2, 0.5, st),
+        lambda: lib.dsr_linear_wgrad_adam(0, N, N, 32, 8, 64, 1, 1.0, N, N, N, N, N, 1e-3, 0.9, 0.999, 1e-8, 1.0, st),
+        lambda: lib.dsr_linear_wgrad_adam(0, one, one, 32, 8, 40, 1, 1.0, one, one, one, N, one, 1e-3, 0.9, 0.999, 1e-8, 1.0, st),  # K % 64
         lambda: lib.dsr_dense2_fwd(N, N, N, 4, 8, N, st),
         lambda: lib.dsr_dense2_bwd(0, N, N, N, N, 4, 8, 32, 0.2, N, N, N, N, N, st),
         lambda: lib.dsr_maxpool2_fwd(0, N, N, 1, 4, 4, 8, st),

@@ -570,6 +570,78 @@ def test_graphed_gan_step_equals_eager(dev, overlap):
             assert torch.equal(a, b), k
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_dense_adam_equals_separate_launches(dev, graph):
+    """optim.FusedAdam(fuse_dense_head=True): dense1.weight's gradient travels as its two 16-bit factors and
+    dsr_linear_wgrad_adam applies Adam inside the contraction (train_GAN.py:52-53 on discriminator.py:54 without the
+    2.1 GB .grad round trip).  Same MFMA fragments in the same order and one shared statement of the Adam arithmetic:
+    after 4 steps every tensor of both networks and both optimisers must equal the two-launch path bit for bit (also when
+    the step replays from a HIP graph); ``.grad`` of that tensor stays None."""
+    Gm, Dm, GANu, optim, steps = P("models.GAN.generator"), P("models.GAN.discriminator"), P("utils.GAN"), P("optim"), P("steps")
+    gsd = filler.fill_state_dict(gan.template(gan.generator_shapes(4, 2)))
+    dsd = filler.fill_state_dict(gan.template(gan.discriminator_shapes((64, 64))))
+    lr = filler.tensor("in:fa_lr", (4, 3, 16, 16), 0.5, 0.5).to(dev)
+    hr = filler.tensor("in:fa_hr", (4, 3, 64, 64)).to(dev)
+    perc = GANu.PerceptualLoss(resize_to=32, crop=28).to(dev)
+
+    def run(fuse):
+        g, d = Gm.Generator(4, 2), Dm.Discriminator((64, 64))
+        g.load_state_dict(gsd), d.load_state_dict(dsd)
+        g.to(dev).train(), d.to(dev).train()
+        og = optim.FusedAdam(g.parameters(), lr=1e-3)
+        od = optim.FusedAdam(d.parameters(), lr=1e-3, fuse_dense_head=fuse)
+        step = lambda: steps.gan_step(g, d, perc, og, od, lr, hr, overlap=True)
+        if graph:
+            step = steps.GraphedStep(step, warmup=2)
+            n = 2
+        else:
+            n = 4
+        for _ in range(n):
+            out = step()
+        torch.cuda.synchronize()
+        assert (d.dense1.weight.grad is None) == fuse
+        return g, d, od, out
+
+    g_a, d_a, od_a, out_a = run(False)
+    g_b, d_b, od_b, out_b = run(True)
+    for a, b in zip(out_a, out_b):
+        assert torch.equal(a, b)
+    for ma, mb in ((g_a, g_b), (d_a, d_b)):
+        for (k, a), (_, b) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            assert torch.equal(a, b), k
+    for a, b in zip(od_a.m + od_a.v, od_b.m + od_b.v):
+        assert torch.equal(a, b)
+    assert int(od_a.step_t) == int(od_b.step_t) == 4
+    # the bf16 shadow of dense1.weight (the next forward's MFMA operand) was refreshed by the fused launch too
+    F = P("functional")
+    sh = F.shadow_for_update(d_b.dense1.weight)
+    assert sh is not None and torch.equal(sh, d_b.dense1.weight.detach().to(torch.bfloat16))
+
+
+def test_dense_head_factors_accumulate_like_autograd(dev):
+    """Two backward passes between zero_grad() and step() (gradient accumulation): the factored gradients are materialised
+    and summed, exactly what autograd's .grad accumulation gives the two-launch optimiser."""
+    Dm, optim, F = P("models.GAN.discriminator"), P("optim"), P("functional")
+    dsd = filler.fill_state_dict(gan.template(gan.discriminator_shapes((32, 32))))
+    xs = [filler.tensor(f"in:acc{i}", (2, 3, 32, 32)).to(dev) for i in range(2)]
+
+    def run(fuse):
+        d = Dm.Discriminator((32, 32))
+        d.load_state_dict(dsd)
+        d.to(dev).train()
+        od = optim.FusedAdam(d.parameters(), lr=1e-3, fuse_dense_head=fuse)
+        od.zero_grad()
+        for x in xs:
+            F.bce_const(d(x), 1.0).backward()
+        od.step()
+        torch.cuda.synchronize()
+        return d
+
+    a, b = run(False), run(True)
+    for (k, u), (_, v) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(u, v), k
+
+
 def test_dip_step_vs_oracle(dev):
     M, D, steps = P("models.DIP"), P("utils.downsampler"), P("steps")
     kw = dict(skip_n33d=16, skip_n33u=16, skip_n11=4, num_scales=3)
