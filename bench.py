@@ -131,7 +131,8 @@ def build_step(workload, dev, world):
             fake = gen(lr)
             loss = F.l1_loss(fake, hr)
             opt_g.zero_grad()
-            loss.backward()
+            with F.batched_wgrad():
+                loss.backward()
             sync_g()
             opt_g.step()
             return loss
@@ -393,7 +394,8 @@ def roofline(step, workload, ms_per_step):
         t, fl, cnt = fam.get(k, (0.0, 0.0, 0))
         # one C-ABI call = one kernel launch, except a strided dgrad on the gather kernel (stride^2 parity classes)
         nl = d[7] * d[7] if (kind == "dgrad" and k.startswith("conv_gemm")) else 1
-        fam[k] = (t + e0.elapsed_time(e1) * 1e-3, fl + conv_flops(d), cnt + nl)
+        flops = sum(conv_flops(q) for q in d) if kind == "wgrad_batch" else conv_flops(d)   # (a grouped launch: many layers)
+        fam[k] = (t + e0.elapsed_time(e1) * 1e-3, fl + flops, cnt + nl)
     if not fam:
         return None
     busy = sum(e0.elapsed_time(e1) for _, e0, e1 in all_log)

@@ -528,6 +528,138 @@ extern "C" int dsr_conv_wgrad(const dsr_conv_desc* d, const void* x, const void*
   return dsr_launch_status("dsr_conv_wgrad");
 }
 
+// ---- batched weight gradients: every 3x3 / stride-1 layer of a backward pass in one contraction launch + one reduction
+// launch (conv_wgrad_tile.hip: conv_wgrad_dma_batch_kernel).  Entries with the same `dws[i]` (a weight used twice in the
+// graph: the discriminator on the real and on the generated batch, train_GAN.py:44-47) must be adjacent; their
+// contributions are summed -- what autograd's accumulation would do with two separate gradients.
+extern "C" int dsr_conv_wgrad_batchable(const dsr_conv_desc* d) {
+  if (!d || check_desc(d)) return 0;
+  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 ? 1 : 0;
+}
+
+namespace {
+struct BatchChunk {
+  int first, count;        // problems [first, first + count)
+  size_t ws_floats;
+};
+// Chunks of <= DSR_WGRAD_BATCH_MAX problems that do not split a group of equal dw; per chunk the pixel range of problem i
+// is cut so that all blocks of the launch carry about the same number of tile steps and there are ~`target` of them.
+int batch_chunks(int count, const dsr_conv_desc* descs, float* const* dws, WgradTileArgs* t, int* ych, BatchChunk* chunks,
+                 int max_chunks) {
+  const char* e = getenv("DSR_WGRAD_BATCH_BLOCKS");      // tuning switch: blocks per batched launch (default 1024 = two rounds of 2 per CU)
+  const long long target = e ? atoi(e) : 1024;
+  int nch = 0, i = 0;
+  while (i < count) {
+    if (nch == max_chunks) return -1;
+    int j = i;
+    while (j < count) {                                   // extend by whole groups
+      int k = j + 1;
+      while (k < count && dws && dws[k] == dws[j]) ++k;
+      if (k - i > DSR_WGRAD_BATCH_MAX) break;
+      j = k;
+    }
+    if (j == i) return -2;                                // one group larger than a launch can hold
+    long long cost = 0;
+    for (int q = i; q < j; ++q) {
+      tile_plan(&descs[q], t[q]);
+      cost += (long long)t[q].ntiles * t[q].tiles_co * t[q].tiles_ci;
+    }
+    long long per = (cost + target - 1) / (target > 0 ? target : 1);
+    if (per < 1) per = 1;
+    size_t wsf = 0;
+    for (int q = i; q < j; ++q) {
+      long long tpb = per < t[q].ntiles ? per : t[q].ntiles;
+      t[q].tiles_per_block = (int)tpb;
+      ych[q] = (int)((t[q].ntiles + tpb - 1) / tpb);
+      wsf += (size_t)ych[q] * 9 * t[q].CoutP * t[q].CinP;
+    }
+    chunks[nch].first = i;
+    chunks[nch].count = j - i;
+    chunks[nch].ws_floats = wsf;
+    ++nch;
+    i = j;
+  }
+  return nch;
+}
+constexpr int kMaxBatchProblems = 256, kMaxBatchChunks = 64;
+}  // namespace
+
+extern "C" size_t dsr_conv_wgrad_batched_workspace(int count, const dsr_conv_desc* descs, float* const* dws) {
+  if (count <= 0 || count > kMaxBatchProblems || !descs) return 0;
+  for (int i = 0; i < count; ++i)
+    if (!dsr_conv_wgrad_batchable(&descs[i])) return 0;
+  static thread_local WgradTileArgs t[kMaxBatchProblems];
+  static thread_local int ych[kMaxBatchProblems];
+  BatchChunk ch[kMaxBatchChunks];
+  const int n = batch_chunks(count, descs, dws, t, ych, ch, kMaxBatchChunks);
+  size_t m = 0;
+  for (int c = 0; c < n; ++c) m = ch[c].ws_floats > m ? ch[c].ws_floats : m;
+  return m * sizeof(float);
+}
+
+extern "C" int dsr_conv_wgrad_batched(int count, const dsr_conv_desc* descs, const void* const* xs, const void* const* dys,
+                                      float* const* dws, void* workspace, size_t ws_bytes, dsr_stream_t s) {
+  if (count <= 0 || count > kMaxBatchProblems) return dsr_fail(DSR_E_ARG, "conv_wgrad_batched: count %d outside 1..%d", count, kMaxBatchProblems);
+  if (!descs || !xs || !dys || !dws || !workspace) return dsr_fail(DSR_E_ARG, "conv_wgrad_batched: null table");
+  for (int i = 0; i < count; ++i) {
+    int rc = check_desc(&descs[i]);
+    if (rc) return rc;
+    if (!dsr_conv_wgrad_batchable(&descs[i])) return dsr_fail(DSR_E_UNSUPPORTED, "conv_wgrad_batched: entry %d is not a 3x3 stride-1 pad-1 convolution", i);
+    if (descs[i].dtype != descs[0].dtype) return dsr_fail(DSR_E_UNSUPPORTED, "conv_wgrad_batched: mixed dtypes");
+    if (!xs[i] || !dys[i] || !dws[i]) return dsr_fail(DSR_E_ARG, "conv_wgrad_batched: null pointer in entry %d", i);
+    if (i && dws[i] == dws[i - 1] && (descs[i].Cin != descs[i - 1].Cin || descs[i].Cout != descs[i - 1].Cout))
+      return dsr_fail(DSR_E_ARG, "conv_wgrad_batched: entries %d and %d share dw but not its shape", i - 1, i);
+    for (int k = 0; k + 1 < i; ++k)
+      if (dws[k] == dws[i] && dws[i - 1] != dws[i]) return dsr_fail(DSR_E_ARG, "conv_wgrad_batched: entries that share dw must be adjacent");
+  }
+  static thread_local WgradTileArgs t[kMaxBatchProblems];
+  static thread_local int ych[kMaxBatchProblems];
+  BatchChunk ch[kMaxBatchChunks];
+  const int n = batch_chunks(count, descs, dws, t, ych, ch, kMaxBatchChunks);
+  if (n < 0) return dsr_fail(DSR_E_UNSUPPORTED, "conv_wgrad_batched: more than %d entries share one dw", DSR_WGRAD_BATCH_MAX);
+  for (int c = 0; c < n; ++c) {
+    if (ws_bytes < ch[c].ws_floats * sizeof(float))
+      return dsr_fail(DSR_E_WORKSPACE, "conv_wgrad_batched: workspace %zu < %zu", ws_bytes, ch[c].ws_floats * sizeof(float));
+    WgradBatchArgs b;
+    WgradReduceBatchArgs r;
+    memset(&b, 0, sizeof(b));
+    memset(&r, 0, sizeof(r));
+    float* ws = (float*)workspace;
+    int blocks = 0, rblocks = 0;
+    for (int q = 0; q < ch[c].count; ++q) {
+      const int i = ch[c].first + q;
+      t[i].x = xs[i];
+      t[i].dy = dys[i];
+      t[i].partial = ws;
+      b.p[q] = t[i];
+      b.first_block[q] = blocks;
+      blocks += ych[i] * t[i].tiles_co * t[i].tiles_ci;
+      const size_t slab = (size_t)9 * t[i].CoutP * t[i].CinP;
+      if (q && dws[i] == dws[i - 1]) {
+        r.e[r.count - 1].splits += ych[i];                 // its slabs follow the previous entry's: one longer sum
+      } else {
+        WgradReduceBatchArgs::Entry& e = r.e[r.count++];
+        e.partial = ws;
+        e.dw = dws[i];
+        e.splits = ych[i];
+        e.Cout = descs[i].Cout;
+        e.Cin = descs[i].Cin;
+        e.CoutP = t[i].CoutP;
+        e.CinP = t[i].CinP;
+        e.first_block = rblocks;
+        rblocks += (int)((slab + 255) / 256);
+      }
+      ws += (size_t)ych[i] * slab;
+    }
+    b.first_block[ch[c].count] = blocks;
+    b.count = ch[c].count;
+    r.total_blocks = rblocks;
+    dsr_launch_wgrad_dma_batch(b, descs[0].dtype, s);
+    dsr_launch_wgrad_reduce_batch(r, s);
+  }
+  return dsr_launch_status("dsr_conv_wgrad_batched");
+}
+
 // ---- measurement aid: the kernel family the dispatch above selects (kept next to it so the two cannot drift far)
 static const char* gemm_name(int nb, long long M = 0, bool fast = false, bool stats = true) {
   if (nb > 64 && dsr_conv_gemm_use_256(M, nb, fast, stats)) return "conv_gemm_kernel<256x256>";

@@ -200,3 +200,34 @@ void dsr_launch_wgrad_reduce(const float* partial, float* dw, int splits, int nt
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx, 1), dim3(256), 0, st, (const float*)scratch, dw, (float*)nullptr, used,
                      used, ntaps, Cout, Cin, CoutP, CinP);
 }
+
+// ---- batched form (3x3): one launch reduces every problem of a dsr_conv_wgrad_batched call.  256 outputs per block;
+// the slabs of an entry are summed in slab order with four independent partial sums (fixed order => deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradReduceBatchArgs r) {
+  int ei = 0;
+  while (ei + 1 < r.count && (int)blockIdx.x >= r.e[ei + 1].first_block) ++ei;
+  ei = __builtin_amdgcn_readfirstlane(ei);
+  const WgradReduceBatchArgs::Entry e = r.e[ei];
+  const int total = 9 * e.CoutP * e.CinP;
+  const int idx = ((int)blockIdx.x - e.first_block) * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const float* p = e.partial + idx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int z = 0;
+  for (; z + 3 < e.splits; z += 4) {
+    s0 += p[(size_t)z * total];
+    s1 += p[(size_t)(z + 1) * total];
+    s2 += p[(size_t)(z + 2) * total];
+    s3 += p[(size_t)(z + 3) * total];
+  }
+  for (; z < e.splits; ++z) s0 += p[(size_t)z * total];
+  const float s = (s0 + s1) + (s2 + s3);
+  const int ci = idx % e.CinP;
+  const int co = (idx / e.CinP) % e.CoutP;
+  const int tap = idx / (e.CinP * e.CoutP);
+  if (ci < e.Cin && co < e.Cout) e.dw[((size_t)co * e.Cin + ci) * 9 + tap] = s;
+}
+
+void dsr_launch_wgrad_reduce_batch(const WgradReduceBatchArgs& r, hipStream_t st) {
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(r.total_blocks), dim3(256), 0, st, r);
+}

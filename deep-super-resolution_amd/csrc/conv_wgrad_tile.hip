@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(const WgradTile
 //     plus an immediate -- the 9-tap loop carries no address arithmetic (the older kernel spent ~6 VALU
 //     instructions per MFMA on it).
 template <int DT>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradTileArgs a) {
+__device__ __forceinline__ void conv_wgrad_dma_body(const WgradTileArgs& a, const int pair, const int ychunk) {
   constexpr int R = 2, HC = 40, HR = R + 2;
   constexpr int XB = HR * HC * 128, YB = R * 32 * 128, STAGE = XB + YB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
@@ -142,7 +142,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradTileA
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it (and what derives from it) in SGPRs
   const int wr = wave >> 1, wc = wave & 1;
   const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
-  const int pair = blockIdx.x;
   const int co0 = (pair / a.tiles_ci) * 64, ci0 = (pair % a.tiles_ci) * 64;
 
   f32x4 acc[9][2][2];
@@ -270,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradTileA
     return c;
   };
 
-  int t = blockIdx.y * a.tiles_per_block;
+  int t = ychunk * a.tiles_per_block;
   int t_end = t + a.tiles_per_block;
   if (t_end > a.ntiles) t_end = a.ntiles;
   TileXY nxt;
@@ -314,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradTileA
     }
   }
 
-  float* P = a.partial + (size_t)blockIdx.y * 9 * a.CoutP * a.CinP;
+  float* P = a.partial + (size_t)ychunk * 9 * a.CoutP * a.CinP;
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
@@ -326,6 +325,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradTileA
           const int co = co0 + wr * 32 + i * 16 + 4 * g + r, ci = ci0 + wc * 32 + j * 16 + l16;
           if (co < a.CoutP && ci < a.CinP) P[((size_t)tp * a.CoutP + co) * a.CinP + ci] = acc[tp][i][j][r];
         }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradTileArgs a) {
+  conv_wgrad_dma_body<DT>(a, blockIdx.x, blockIdx.y);
+}
+
+// Grouped form: up to DSR_WGRAD_BATCH_MAX problems (layers) in ONE launch.  A 64 -> 64 layer has a single 64 x 64 output
+// tile pair, so a launch of its own can only fill the chip by cutting the pixel range into ~256 chunks, each of which
+// writes a 147 KB fp32 partial slab (37 MB per layer, read back by a two-pass reduction): the generator's 33 trunk layers
+// spent 62 us in the contraction and 19 us in reductions EACH.  With all layers of a backward pass in one grid the
+// parallelism comes from the layers and ~30 chunks per layer suffice.  Block -> (problem, pair, chunk) by a uniform scan
+// of the first-block table (scalar code, <= 36 steps).
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_dma_batch_kernel(const WgradBatchArgs b) {
+  int pi = 0;
+  while (pi + 1 < b.count && (int)blockIdx.x >= b.first_block[pi + 1]) ++pi;
+  pi = __builtin_amdgcn_readfirstlane(pi);
+  const WgradTileArgs a = b.p[pi];
+  const int local = (int)blockIdx.x - b.first_block[pi];
+  const int pairs = a.tiles_co * a.tiles_ci;
+  conv_wgrad_dma_body<DT>(a, local % pairs, local / pairs);
 }
 
 // ------------------------------------------------------------------ 3x3 / stride 2, same LDS-DMA pipeline
@@ -532,6 +553,14 @@ static void launch_dt(const WgradTileArgs& a, int KH, int stride, dim3 grid, hip
     hipLaunchKernelGGL((conv_wgrad_dma_s2_kernel<DT>), grid, dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((conv_wgrad_tile_kernel<DT, 1, 1, 1>), grid, dim3(256), 0, st, a);
+}
+
+void dsr_launch_wgrad_dma_batch(const WgradBatchArgs& b, int dtype, hipStream_t st) {
+  const int blocks = b.first_block[b.count];
+  if (dtype == DSR_DTYPE_BF16)
+    hipLaunchKernelGGL((conv_wgrad_dma_batch_kernel<DSR_DTYPE_BF16>), dim3(blocks), dim3(256), 0, st, b);
+  else
+    hipLaunchKernelGGL((conv_wgrad_dma_batch_kernel<DSR_DTYPE_F16>), dim3(blocks), dim3(256), 0, st, b);
 }
 
 void dsr_launch_wgrad_tile(const WgradTileArgs& a, int KH, int stride, int ychunks, int dtype, hipStream_t st) {

@@ -99,6 +99,25 @@ struct WgradTileArgs {
   int tiles_y, tiles_x, ntiles, tiles_per_block;
   unsigned x_bytes, dy_bytes;
 };
+// grouped launch of the 3x3 / stride-1 kernel: problems by value in the kernel-argument segment (4 KB limit)
+#define DSR_WGRAD_BATCH_MAX 36
+struct WgradBatchArgs {
+  WgradTileArgs p[DSR_WGRAD_BATCH_MAX];
+  int first_block[DSR_WGRAD_BATCH_MAX + 1];
+  int count;
+};
+static_assert(sizeof(WgradBatchArgs) <= 4096, "kernel arguments are limited to 4 KB");
+void dsr_launch_wgrad_dma_batch(const WgradBatchArgs& b, int dtype, hipStream_t st);
+// one reduction launch for a batch: entry e sums `splits` consecutive slabs into dw (PyTorch [co][ci][kh][kw] layout)
+struct WgradReduceBatchArgs {
+  struct Entry {
+    const float* partial;
+    float* dw;
+    int splits, Cout, Cin, CoutP, CinP, first_block;
+  } e[DSR_WGRAD_BATCH_MAX];
+  int count, total_blocks;
+};
+void dsr_launch_wgrad_reduce_batch(const WgradReduceBatchArgs& r, hipStream_t st);
 // returns the number of partial slabs (ychunks) the launch will write, 0 if the shape is not handled
 int dsr_wgrad_tile_plan(int KH, int KW, int stride, int N, int OH, int OW, int CinP, int CoutP, WgradTileArgs* a);
 void dsr_launch_wgrad_tile(const WgradTileArgs& a, int KH, int stride, int ychunks, int dtype, hipStream_t st);

@@ -54,7 +54,7 @@ KERNEL_LOG = None          # set to a list to record (kind, desc-tuple, start_ev
 _OPS = {"fwd": 0, "dgrad": 1, "wgrad": 2}
 
 
-def _timed(kind, desc, fn, ep=None):
+def _timed(kind, desc, fn, ep=None, name=None):
     """Run one C-ABI conv call; when KERNEL_LOG is a list, bracket it with HIP events on the launch stream."""
     if KERNEL_LOG is None:
         return fn()
@@ -62,7 +62,8 @@ def _timed(kind, desc, fn, ep=None):
     e0.record()
     rc = fn()
     e1.record()
-    name = _lib.lib().dsr_conv_kernel_name(C.byref(desc), _OPS[kind], C.byref(ep) if ep is not None else None).decode()
+    if name is None:
+        name = _lib.lib().dsr_conv_kernel_name(C.byref(desc), _OPS[kind], C.byref(ep) if ep is not None else None).decode()
     KERNEL_LOG.append((kind, (desc.N, desc.H, desc.W, desc.Cin, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad), e0, e1, name))
     return rc
 
@@ -169,7 +170,93 @@ def _reduce_blocks(p):
     return blocks, rpb.value
 
 
-def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape):
+_wgrad_batch = None      # the open batched_wgrad context (per process: backward passes are issued from one thread here)
+
+
+class batched_wgrad:
+    """``with batched_wgrad(): loss.backward()`` -- every 3x3 stride-1 weight gradient of that backward pass is formed by ONE
+    grouped contraction launch and one reduction launch when the block exits (dsr_conv_wgrad_batched), instead of one
+    contraction + two reduction launches per layer.  The SRGAN trunk is 33 such layers with a single 64x64 output tile
+    each (generator.py:7-25,52): alone, a layer can only fill the chip by cutting its pixels into ~256 chunks and
+    reducing 37 MB of partials; together ~30 chunks per layer do.  A weight that appears twice in the graph (the
+    discriminator on the real and the generated batch, train_GAN.py:44-47) gets both contributions summed inside the
+    reduction, which also replaces autograd's elementwise accumulation.
+
+    Inside the block a layer's backward returns its (still unwritten) gradient tensor, so nothing may READ a weight's
+    .grad before the block exits: hooks on those parameters, and accumulation into an existing .grad -- a weight whose
+    .grad is already set is therefore computed at once, unbatched.  On exit each parameter's .grad is checked to be the
+    tensor the launch wrote (autograd may have cloned it) and repaired if not."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+        self.items = {}          # id(weight) -> [weight, returned tensor, alias of it, [(desc, x, dy), ...]]
+
+    def __enter__(self):
+        global _wgrad_batch
+        self.outer = _wgrad_batch
+        if self.enabled and self.outer is None:
+            _wgrad_batch = self
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _wgrad_batch
+        if _wgrad_batch is self:
+            _wgrad_batch = None
+            if et is None:
+                self.flush()
+            self.items = {}
+        return False
+
+    def add(self, weight, desc, x, dy, wshape):
+        """The gradient tensor to return for this use of `weight` (None for a second use: its contribution joins the first)."""
+        ent = self.items.get(id(weight))
+        if ent is not None:
+            ent[3].append((desc, x, dy))
+            return None
+        dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
+        # (the alias shares dw's storage through a tensor object of its own: autograd takes over a gradient only while
+        # nobody else holds the very tensor it was handed)
+        self.items[id(weight)] = [weight, None, dw.detach(), [(desc, x, dy)]]
+        return dw
+
+    def flush(self):
+        if not self.items:
+            return
+        lib = _lib.lib()
+        ents = list(self.items.values())
+        by_dtype = {}
+        for ent in ents:
+            by_dtype.setdefault(ent[3][0][0].dtype, []).append(ent)
+        for group in by_dtype.values():
+            descs, xs, dys, dws = [], [], [], []
+            for weight, _, alias, uses in group:
+                for desc, x, dy in uses:
+                    descs.append(desc)
+                    xs.append(x.data_ptr())
+                    dys.append(dy.data_ptr())
+                    dws.append(alias.data_ptr())
+            n = len(descs)
+            darr = (_lib.ConvDesc * n)(*descs)
+            xa, ya, wa = (C.c_void_p * n)(*xs), (C.c_void_p * n)(*dys), (C.c_void_p * n)(*dws)
+            wsz = lib.dsr_conv_wgrad_batched_workspace(n, darr, wa)
+            ws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=group[0][2].device)
+            if KERNEL_LOG is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(lib.dsr_conv_wgrad_batched(n, darr, xa, ya, wa, _ptr(ws), wsz, _stream()))
+            if KERNEL_LOG is not None:
+                e1.record()
+                KERNEL_LOG.append(("wgrad_batch", [(d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad) for d in descs],
+                                   e0, e1, "conv_wgrad_dma_batch_kernel"))
+        for weight, _, alias, uses in ents:
+            g = weight.grad
+            if g is None:
+                continue                                  # (nobody kept the gradient: e.g. torch.autograd.grad)
+            if g.data_ptr() != alias.data_ptr():
+                g.copy_(alias)                            # autograd stored a copy made before the launch: refresh it
+
+
+def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape, weight=None):
     lib = _lib.lib()
     dx = dw = None
     if need_dx:
@@ -178,6 +265,10 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape):
         ws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=x.device)
         check(_timed("dgrad", desc, lambda: lib.dsr_conv_dgrad(C.byref(desc), _ptr(dy), _ptr(wd), _ptr(dx), _ptr(ws), wsz,
                                                                  _stream())))
+    if (need_dw and _wgrad_batch is not None and weight is not None and weight.grad is None
+            and not getattr(weight, "_post_accumulate_grad_hooks", None)      # (a hook would read the gradient at once)
+            and lib.dsr_conv_wgrad_batchable(C.byref(desc))):
+        return dx, _wgrad_batch.add(weight, desc, x, dy, weight_shape)
     if need_dw:
         dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
         wsz = lib.dsr_conv_wgrad_workspace(C.byref(desc))
@@ -280,6 +371,7 @@ class ConvAct(torch.autograd.Function):
                                                                     _stream()), ep))
         ctx.desc, ctx.cfg, ctx.ps, ctx.act = desc, cfg, ps, act
         ctx.wshape = tuple(weight.shape)
+        ctx.weight_ref = weight
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, y, wd, prelu if prelu is not None else torch.empty(0, device=x.device))
         return y
@@ -306,7 +398,7 @@ class ConvAct(torch.autograd.Function):
             ws = torch.empty(wsz, dtype=torch.uint8, device=x.device)
             check(_timed("wgrad", desc, lambda: lib.dsr_conv_first_bwd(
                 C.byref(desc), _ptr(x), _ptr(dout), _ptr(y), ctx.act, float(ctx.cfg.get("slope", 0.0)), _ptr(dw), _ptr(db),
-                _ptr(ws), wsz, _stream())))
+                _ptr(ws), wsz, _stream()), name="conv_first_bwd_kernel"))
             return None, dw, db, None, None
         if ctx.act == ACT_NONE and not ctx.ps:
             dy = dout
@@ -329,7 +421,8 @@ class ConvAct(torch.autograd.Function):
                 check(lib.dsr_pw_sum_rows(_ptr(part), blocks, 2 * cyp, cyp, cyp, 1.0, _ptr(chan), 0, 1, _stream()))
                 dprelu = torch.empty(1, dtype=torch.float32, device=x.device)
                 check(lib.dsr_pw_sum_rows(_ptr(chan), cyp, 1, 0, 1, 1.0, _ptr(dprelu), 0, 0, _stream()))
-        dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape)
+        dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape,
+                                 getattr(ctx, "weight_ref", None))
         return dx, dw, db, dprelu, None
 
 
@@ -402,6 +495,7 @@ class ConvBNAct(torch.autograd.Function):
                                     float(cfg.get("slope", 0.0)), _ptr(prelu), _stream()))
         ctx.desc, ctx.cfg, ctx.act, ctx.train, ctx.count = desc, cfg, act, train, count
         ctx.wshape = tuple(weight.shape)
+        ctx.weight_ref = weight
         ctx.has_res = residual is not None
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, y, wd, scale, shift, mean, rstd,
@@ -436,7 +530,8 @@ class ConvBNAct(torch.autograd.Function):
         check(lib.dsr_pw_bn_act_bwd_apply(_dt(x), _ptr(dout), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
                                           _ptr(c1), _ptr(c2), _ptr(dy), p, cp, ctx.act, slope, _ptr(prelu),
                                           int(ctx.train), _stream()))
-        dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape)
+        dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape,
+                                 getattr(ctx, "weight_ref", None))
         db = None
         if ctx.has_bias and not ctx.train:
             # a bias in front of a train-mode BatchNorm has an analytically zero gradient (the reference holds ~1e-9
@@ -467,6 +562,7 @@ class ConvOutNCHW(torch.autograd.Function):
                                                                     _stream()), ep))
         ctx.desc, ctx.act = desc, act
         ctx.wshape = tuple(weight.shape)
+        ctx.weight_ref = weight
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, out, wd)
         return out
@@ -480,7 +576,8 @@ class ConvOutNCHW(torch.autograd.Function):
         dy = torch.empty((n, h, w, r8(c)), dtype=x.dtype, device=x.device)
         check(_lib.lib().dsr_pw_act_bwd_nchw(_dt(x), _ptr(dout), _ptr(out), _ptr(dy), n, c, h, w, r8(c), ctx.act,
                                              _stream()))
-        dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape)
+        dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape,
+                                 getattr(ctx, "weight_ref", None))
         db = _colsum(dy, c) if ctx.has_bias else None
         return dx, dw, db, None
 
@@ -628,6 +725,15 @@ def mark_shadow_current(weight):
         _shadow_cache[key] = (_version(weight), hit[1], hit[2])
 
 
+def _awaits_allreduce(param):
+    """True when a data-parallel run will average `param`.grad with a collective after backward (dist.GradSync) -- such a
+    gradient has to exist as a tensor; the dense head's matrix is exempt when its factors are gathered instead."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return False
+    return not getattr(param, "_dsr_grad_global", False)
+
+
 def dp_world_for(param):
     """World size when `param`'s gradient is produced already averaged over the ranks by its own backward
     (`param._dsr_grad_global`, set by dist.GradSync.attach for the dense head's big matrix), else 0."""
@@ -725,7 +831,7 @@ class DenseHead(torch.autograd.Function):
                 xt, dyt16, works = gather
             ranks = max(ctx.dp_world, 1) if gather is not None else 1
             fac = GradFactors(_dt(x), dyt16, xt, bp, o, k, ranks, 1.0 / ranks, works)
-            if getattr(ctx.w1, "_dsr_defer_wgrad", False) and k % 64 == 0:
+            if getattr(ctx.w1, "_dsr_defer_wgrad", False) and k % 64 == 0 and not _awaits_allreduce(ctx.w1):
                 # optim.FusedAdam(fuse_dense_head=True): dW1 = dyT x is a rank-(64 R) product -- hand the two factors to
                 # the optimiser, whose dsr_linear_wgrad_adam launch forms each tile of it in registers and applies Adam
                 # there; the 2.1 GB gradient (config 3) is neither written nor read back

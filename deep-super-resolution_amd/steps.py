@@ -13,7 +13,8 @@ def gen_l1_step(gen, opt, lr_patches, hr_patches):
     fake = gen(lr_patches)
     loss = F.l1_loss(fake, hr_patches)
     opt.zero_grad()
-    loss.backward()
+    with F.batched_wgrad():              # the 35 3x3 weight gradients of the generator: one grouped launch at the end
+        loss.backward()
     opt.step()
     return loss.detach(), fake.detach()
 
@@ -40,7 +41,8 @@ def _mark(label, stream):
         TRACE.append((label, ev))
 
 
-def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g=None, sync_d=None, overlap=True):
+def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g=None, sync_d=None, overlap=True,
+             batch_wgrad=None):
     """train_GAN.py:38-71.  Returns (loss_D, loss_G, fake) as device tensors (no host sync here).
 
     Once `fake` exists the reference's two halves are independent: the D step (:44-53) reads only `fake.detach()`,
@@ -52,6 +54,9 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
     # train_GAN.py:46 and :56 evaluate gen(lr_patches) twice with the same weights and batch statistics -- the
     # two outputs are bit-identical and only the BatchNorm running statistics notice the second call.  One forward
     # (with the autograd graph the G step needs) + a double running-stat update is exactly equivalent.
+    if batch_wgrad is None:
+        import os
+        batch_wgrad = os.environ.get("DSR_WGRAD_BATCH", "1") != "0"    # tuning switch: 0 = one weight-gradient launch per layer
     main = torch.cuda.current_stream(hr_patches.device)
     side = _side_stream(hr_patches.device) if overlap else main
     hr_feat = real_feat = None
@@ -79,7 +84,8 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
         real_d, fake_d = disc.forward_pair(hr_patches, fake_det, fa=real_feat)   # :44, :47 (BN statistics per batch, as there)
         loss_d = F.add_losses(F.bce_const(real_d, 1.0), F.bce_const(fake_d, 0.0))  # :48, utils/GAN.py:101-105
         opt_d.zero_grad()                                        # :51 (gan_D.zero_grad())
-        loss_d.backward()                                        # :52
+        with F.batched_wgrad(batch_wgrad):                       # (D's stride-1 layers, real + generated batch summed)
+            loss_d.backward()                                    # :52
         _mark("D: backward done", torch.cuda.current_stream())
         if sync_d is not None:
             sync_d()
@@ -104,7 +110,8 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
     content = perceptual.content(fake, hr_patches, hr_feat)      # the only term of :59 with a gradient path
     opt_g.zero_grad()                                            # :62
     _mark("main: VGG content loss forward done", main)
-    content.backward()                                           # :63 (d adversarial / d generator == 0, see above)
+    with F.batched_wgrad(batch_wgrad):                           # the generator's 35 3x3 layers: one grouped launch
+        content.backward()                                       # :63 (d adversarial / d generator == 0, see above)
     _mark("main: G backward done", main)
     if sync_g is not None:
         sync_g()
@@ -173,6 +180,7 @@ class DipRunner:
         out_hr = self.net(self.net_input)                        # :60
         out_lr = self.down(out_hr)                               # :62
         loss = F.mse_loss(out_lr, self.lr_image)                 # :65
-        F.scale_loss(loss, self.loss_scale).backward()           # :68
+        with F.batched_wgrad():
+            F.scale_loss(loss, self.loss_scale).backward()       # :68
         self.opt.step()
         return loss.detach(), out_hr.detach()

@@ -106,6 +106,14 @@ int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const void* dout, 
 /* Which kernel the dispatcher launches for this descriptor (measurement aid: bench.py labels its HIP-event timings
  * with it so they can be matched against rocprofv3's kernel names).  op: 0 forward, 1 dgrad, 2 wgrad.  `e` may be
  * NULL (no statistics, no pixel shuffle, NHWC output).  Returns a static string; never NULL. */
+/* Every 3x3 / stride-1 / pad-1 weight gradient of a backward pass in one contraction launch + one reduction launch
+ * (replaces the per-layer weight-gradient kernels of loss.backward(), train_GAN.py:52,63).  Entries whose dws[i] are equal
+ * must be adjacent and are summed into that one gradient (a weight applied to two batches).  All entries share one dtype.
+ * dsr_conv_wgrad_batchable: 1 if the shape is taken; the workspace size depends on the whole table. */
+int dsr_conv_wgrad_batchable(const dsr_conv_desc* d);
+size_t dsr_conv_wgrad_batched_workspace(int count, const dsr_conv_desc* descs, float* const* dws);
+int dsr_conv_wgrad_batched(int count, const dsr_conv_desc* descs, const void* const* xs, const void* const* dys,
+                           float* const* dws, void* workspace, size_t ws_bytes, dsr_stream_t s);
 const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, const dsr_epilogue* e);
 
 /* ------------------------------------------------------------------ pointwise / reductions (pointwise.hip)

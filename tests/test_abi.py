@@ -120,6 +120,9 @@ def test_bad_arguments_return_codes_not_crashes(so):
         lambda: lib.dsr_linear_dgrad(0, N, N, N, 4, 8, 64, st),
         lambda: lib.dsr_linear_wgrad(0, N, N, N, 32, 8, 64, st),
         lambda: lib.dsr_linear_wgrad_gathered(0, N, N, N, 32, 8, 64, 2, 0.5, st),
+        lambda: lib.dsr_conv_wgrad_batched(1, None, None, None, None, N, 0, st),
+        lambda: lib.dsr_conv_wgrad_batched(0, ctypes.byref(d), None, None, None, N, 0, st),
+        lambda: lib.dsr_conv_wgrad_batched(100000, ctypes.byref(d), None, None, None, N, 0, st),
         lambda: lib.dsr_linear_wgrad_adam(0, N, N, 32, 8, 64, 1, 1.0, N, N, N, N, N, 1e-3, 0.9, 0.999, 1e-8, 1.0, st),
         lambda: lib.dsr_linear_wgrad_adam(0, one, one, 32, 8, 40, 1, 1.0, one, one, one, N, one, 1e-3, 0.9, 0.999, 1e-8, 1.0, st),  # K % 64
         lambda: lib.dsr_dense2_fwd(N, N, N, 4, 8, N, st),

@@ -574,3 +574,66 @@ def test_conv_dgrad_s2_single_launch_equals_four_launches(dev, n, h, w, cin, cou
     got = outs[1].float().permute(0, 3, 1, 2).cpu().double()
     assert tuple(ref.shape) == tuple(got.shape)
     assert float((got - ref).abs().max() / ref.abs().max()) < 1.2e-2
+
+
+def test_conv_wgrad_batched_equals_per_layer_launches(dev):
+    """dsr_conv_wgrad_batched (every 3x3 stride-1 weight gradient of a backward pass in one grouped launch) against
+    dsr_conv_wgrad per layer and a float64 reference: mixed shapes (one 64x64 tile pair up to 3x2 pairs, ragged image
+    sizes, reflect padding as in models/DIP/skip.py), two entries that share one dw (a weight applied to two batches:
+    discriminator on real + generated, train_GAN.py:44-47 -> the SUM of both gradients), and more entries than one launch
+    holds (chunking).  fp32 sums in a different split order: equal to ~1e-6 relative, not bitwise."""
+    import ctypes as C
+    L = P("_lib")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    shapes = [(2, 24, 40, 64, 64, 0), (1, 17, 33, 64, 128, 0), (2, 16, 16, 192, 96, 0), (1, 20, 28, 32, 64, 1),
+              (2, 24, 40, 64, 64, 0)] + [(1, 12, 20, 64, 64, 0)] * 40      # 45 weights > DSR_WGRAD_BATCH_MAX
+    descs, xs, dys, dws, refs = [], [], [], [], []
+    for i, (n, h, w, cin, cout, pm) in enumerate(shapes):
+        uses = 2 if i == 1 else 1                        # weight 1 is applied to two batches
+        dw = torch.full((cout, cin, 3, 3), float("nan"), dtype=torch.float32, device=dev)
+        ref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64)
+        for u in range(uses):
+            nn_ = n + u                                  # (the two batches need not have one size)
+            x = bfr(torch.rand(nn_, cin, h, w, generator=g) - 0.5)
+            dy = bfr(torch.rand(nn_, cout, h, w, generator=g) - 0.5)
+            xp = TF.pad(x.double(), (1, 1, 1, 1), mode="reflect" if pm == 1 else "constant")
+            ref += torch.nn.grad.conv2d_weight(xp, (cout, cin, 3, 3), dy.double())
+            descs.append(L.ConvDesc(L.BF16, nn_, h, w, cin, cout, 3, 3, 1, 1, pm))
+            xs.append(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev))
+            dys.append(dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev))
+            dws.append(dw)
+        refs.append((dw, ref))
+    k = len(descs)
+    assert all(lib.dsr_conv_wgrad_batchable(C.byref(d)) == 1 for d in descs)
+    assert lib.dsr_conv_wgrad_batchable(C.byref(L.ConvDesc(L.BF16, 1, 16, 16, 64, 64, 3, 3, 2, 1, 0))) == 0
+    darr = (L.ConvDesc * k)(*descs)
+    xa = (C.c_void_p * k)(*[t.data_ptr() for t in xs])
+    ya = (C.c_void_p * k)(*[t.data_ptr() for t in dys])
+    wa = (C.c_void_p * k)(*[t.data_ptr() for t in dws])
+    wsz = lib.dsr_conv_wgrad_batched_workspace(k, darr, wa)
+    assert wsz > 0
+    ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+    L.check(lib.dsr_conv_wgrad_batched(k, darr, xa, ya, wa, ws.data_ptr(), wsz, st))
+    assert lib.dsr_conv_wgrad_batched(k, darr, xa, ya, wa, ws.data_ptr(), wsz // 2, st) < 0      # workspace too small
+    torch.cuda.synchronize()
+    # per-layer launches of the same problems
+    single = []
+    for d, x, dy in zip(descs, xs, dys):
+        o = torch.empty(d.Cout, d.Cin, 3, 3, dtype=torch.float32, device=dev)
+        w1 = lib.dsr_conv_wgrad_workspace(C.byref(d))
+        s1 = torch.empty(w1, dtype=torch.uint8, device=dev)
+        L.check(lib.dsr_conv_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), o.data_ptr(), s1.data_ptr(), w1, st))
+        single.append(o)
+    torch.cuda.synchronize()
+    j = 0
+    for i, (dw, ref) in enumerate(refs):
+        uses = 2 if i == 1 else 1
+        per_layer = sum(single[j:j + uses])
+        j += uses
+        got = dw.cpu().double()
+        assert torch.isfinite(got).all(), i
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) < 2e-5 * scale + 1e-4, i          # fp32 accumulation of exact bf16 products
+        assert float((got - per_layer.cpu().double()).abs().max()) < 2e-5 * scale + 1e-4, i

@@ -723,7 +723,7 @@ def test_two_rank_gan_step_rehearsal(dev):
     sums = {}
     for mode in ("1", "0"):      # dense1 gradient by all-gathered factors (default) | by plain all-reduce
         r = subprocess.run(cmd, cwd=root, env=dict(env, DSR_DP_FACTOR_GATHER=mode), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.returncode == 0, r.stderr[-6000:]
         assert "rehearsal: parameters identical on all ranks" in r.stderr
         out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert out["n_gpus"] == 2 and out["value"] > 0
@@ -753,7 +753,7 @@ def test_rccl_single_rank_gan_step(dev):
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             env.pop(k, None)
         r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.returncode == 0, r.stderr[-6000:]
         out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert out["n_gpus"] == 1 and out["value"] > 0
         sums[tag] = {m.group(1): float(m.group(2)) for m in re.finditer(r"checksum (\w+) ([0-9.e+-]+)", r.stderr)}
@@ -822,3 +822,74 @@ def test_full_size_gan_step_bookkeeping(dev):
         del gen, disc, og, od
     a, b = results
     assert all(abs(x - y) <= 1e-6 * max(1.0, abs(x)) for x, y in zip(a, b)), (a, b)
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_batched_wgrad_step_equals_per_layer_step(dev, overlap):
+    """steps.gan_step with functional.batched_wgrad (one grouped weight-gradient launch per backward pass; the
+    discriminator's real + generated contributions summed inside its reduction) against the same step with one launch per
+    layer and autograd's own accumulation: the same gradients up to fp32 summation order, so after one step every parameter
+    moves by the same Adam update to ~1e-6 (a flipped sign of a near-zero gradient would show as 2 lr = 2e-3)."""
+    Gm, Dm, GANu, optim, steps = P("models.GAN.generator"), P("models.GAN.discriminator"), P("utils.GAN"), P("optim"), P("steps")
+    gsd = filler.fill_state_dict(gan.template(gan.generator_shapes(4, 2)))
+    dsd = filler.fill_state_dict(gan.template(gan.discriminator_shapes((64, 64))))
+    lr = filler.tensor("in:bw_lr", (4, 3, 16, 16), 0.5, 0.5).to(dev)
+    hr = filler.tensor("in:bw_hr", (4, 3, 64, 64)).to(dev)
+    perc = GANu.PerceptualLoss(resize_to=32, crop=28).to(dev)
+    F = P("functional")
+
+    def run(batch):
+        g, d = Gm.Generator(4, 2), Dm.Discriminator((64, 64))
+        g.load_state_dict(gsd), d.load_state_dict(dsd)
+        g.to(dev).train(), d.to(dev).train()
+        og, od = optim.FusedAdam(g.parameters(), lr=1e-3), optim.FusedAdam(d.parameters(), lr=1e-3)
+        out = steps.gan_step(g, d, perc, og, od, lr, hr, overlap=overlap, batch_wgrad=batch)
+        torch.cuda.synchronize()
+        grads = {("g." + k): p.grad.detach().clone() for k, p in g.named_parameters() if p.grad is not None}
+        grads.update({("d." + k): p.grad.detach().clone() for k, p in d.named_parameters() if p.grad is not None})
+        return g, d, out, grads
+
+    g_a, d_a, out_a, gr_a = run(False)
+    g_b, d_b, out_b, gr_b = run(True)
+    assert F._wgrad_batch is None
+    assert set(gr_a) == set(gr_b)
+    for k in gr_a:
+        a, b = gr_a[k].double(), gr_b[k].double()
+        assert torch.isfinite(b).all(), k
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12, k
+    for a, b in zip(out_a, out_b):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    for ma, mb in ((g_a, g_b), (d_a, d_b)):
+        for (k, a), (_, b) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            if a.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+                # Adam's first step moves a parameter by lr * g / (|g| + eps): only where |g| ~ eps = 1e-8 can a 1e-6
+                # relative change of g show; allow a few such elements
+                bad = ((a - b).abs() > 2e-5).float().mean().item()
+                assert bad < 1e-3, (k, bad)
+
+
+def test_batched_wgrad_leaves_existing_grad_and_exceptions_alone(dev):
+    """A weight whose .grad is already set (accumulation over two backward passes) is not batched -- autograd adds into it at
+    once, which needs the finished gradient -- and an exception inside the block discards the batch."""
+    Gm, F = P("models.GAN.generator"), P("functional")
+    gsd = filler.fill_state_dict(gan.template(gan.generator_shapes(4, 2)))
+    x = filler.tensor("in:bw2", (2, 3, 16, 16), 0.5, 0.5).to(dev)
+    hr = filler.tensor("in:bw2_hr", (2, 3, 64, 64)).to(dev)
+
+    def grads(two_pass, batch):
+        g = Gm.Generator(4, 2)
+        g.load_state_dict(gsd)
+        g.to(dev).train()
+        for _ in range(2 if two_pass else 1):
+            with F.batched_wgrad(batch):
+                F.l1_loss(g(x), hr).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in g.named_parameters() if p.grad is not None}
+
+    a, b = grads(True, False), grads(True, True)
+    for k in a:
+        assert float((a[k].double() - b[k].double()).abs().max()) <= 2e-5 * float(a[k].abs().max()) + 1e-12, k
+    with pytest.raises(ZeroDivisionError):
+        with F.batched_wgrad():
+            1 / 0
+    assert F._wgrad_batch is None
