@@ -34,6 +34,8 @@ _DESC = C.POINTER(ConvDesc)
 SIGNATURES = {
     "dsr_last_error": (C.c_char_p, []),
     "dsr_abi_version": (_I, []),
+    "dsr_conv_dgrad_add_supported": (_I, [_DESC]),
+    "dsr_conv_dgrad_add": (_I, [_DESC, _P, _P, _P, _P, _P]),
     "dsr_conv_wgrad_batchable": (_I, [_DESC]),
     "dsr_conv_wgrad_batched_workspace": (_Z, [_I, _DESC, C.POINTER(C.c_void_p)]),
     "dsr_conv_wgrad_batched": (_I, [_I, _DESC, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, _Z, _P]),
@@ -107,7 +109,7 @@ _lib = None
 # bench.py's roofline leg: a list here makes every launching entry point record (name, start_event, end_event) on the
 # stream it launches on (torch's current stream), so that the GPU-busy share of a step can be told from launch gaps.
 LAUNCH_LOG = None
-_NO_LAUNCH = ("dsr_last_error", "dsr_abi_version", "dsr_conv_kernel_name", "dsr_conv_wgrad_batchable", "dsr_conv_wgrad_batched_workspace", "dsr_conv_fwd_affine_supported",
+_NO_LAUNCH = ("dsr_last_error", "dsr_abi_version", "dsr_conv_kernel_name", "dsr_conv_wgrad_batchable", "dsr_conv_wgrad_batched_workspace", "dsr_conv_dgrad_add_supported", "dsr_conv_fwd_affine_supported",
               "dsr_conv_first_bwd_supported", "dsr_conv_first_bwd_workspace", "dsr_conv_out_size", "dsr_conv_stats_rows",
               "dsr_conv_packed_elems", "dsr_conv_dgrad_workspace", "dsr_conv_wgrad_workspace", "dsr_pw_scratch_rows",
               "dsr_pw_reduce_blocks", "dsr_linear_fwd_workspace", "dsr_ssim_blocks")

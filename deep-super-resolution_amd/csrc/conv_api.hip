@@ -285,6 +285,27 @@ __global__ void reflect_fold_kernel(const unsigned short* __restrict__ dxp, unsi
   *reinterpret_cast<U4*>(dx + pix * Cp + ch * 8) = pack8<DT>(acc);
 }
 
+static void launch_c64_dgrad(const dsr_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, void* dx,
+                             dsr_stream_t s) {
+  C64Args c;
+  memset(&c, 0, sizeof(c));
+  c.CoutP = 64;
+  c.x = dy;
+  c.w = w_dgrad;
+  c.y = dx;
+  c.res = addend;                       // dx = dgrad(dy) + addend: the skip path's gradient rides in the epilogue
+  c.flags = addend ? DSR_F_RESIDUAL : 0;
+  c.H = d->H;
+  c.W = d->W;
+  c.act = DSR_ACT_NONE;
+  for (int kh = 0; kh < 3; ++kh)
+    for (int kw = 0; kw < 3; ++kw) {
+      c.tap_y[kh * 3 + kw] = 2 - kh;
+      c.tap_x[kh * 3 + kw] = 2 - kw;
+    }
+  dsr_launch_conv_c64(c, d->N, d->dtype, s);
+}
+
 extern "C" size_t dsr_conv_dgrad_workspace(const dsr_conv_desc* d) {
   if (check_desc(d)) return 0;
   if (d->pad_mode == DSR_PAD_ZERO || d->pad == 0) return 0;
@@ -312,21 +333,7 @@ extern "C" int dsr_conv_dgrad(const dsr_conv_desc* d, const void* dy, const void
     target = workspace;
   }
   if (is_c64(d)) {   // mirrored taps on the [tap][ci][co] weight image
-    C64Args c;
-    memset(&c, 0, sizeof(c));
-    c.CoutP = 64;
-    c.x = dy;
-    c.w = w_dgrad;
-    c.y = dx;
-    c.H = d->H;
-    c.W = d->W;
-    c.act = DSR_ACT_NONE;
-    for (int kh = 0; kh < 3; ++kh)
-      for (int kw = 0; kw < 3; ++kw) {
-        c.tap_y[kh * 3 + kw] = 2 - kh;
-        c.tap_x[kh * 3 + kw] = 2 - kw;
-      }
-    dsr_launch_conv_c64(c, d->N, d->dtype, s);
+    launch_c64_dgrad(d, dy, w_dgrad, nullptr, dx, s);
     return dsr_launch_status("dsr_conv_dgrad(c64)");
   }
   if (is_tail9(d)) {   // the generator's 9x9 64->3 tail: Toeplitz K = (kw, co) mapping (conv_smalln.hip)
@@ -526,6 +533,21 @@ extern "C" int dsr_conv_wgrad(const dsr_conv_desc* d, const void* x, const void*
   dsr_launch_wgrad(a, d->dtype, s);
   dsr_launch_wgrad_reduce(a.partial, dw, a.splits, d->KH * d->KW, d->Cout, d->Cin, a.CoutP, a.CinP, s);
   return dsr_launch_status("dsr_conv_wgrad");
+}
+
+// dx = dgrad(dy) + addend in one launch: a residual block's input receives the gradient of its conv path AND of its skip
+// path (generator.py:24: `return x + z`); the sum otherwise costs an elementwise pass over three tensors per block.  Taken
+// by the 64 -> 64 3x3 kernel (its folded epilogue adds a residual tile: round(bf16(acc) + addend), the same two roundings
+// as a separate add); other shapes: DSR_E_UNSUPPORTED, the caller adds itself.
+extern "C" int dsr_conv_dgrad_add_supported(const dsr_conv_desc* d) { return d && !check_desc(d) && is_c64(d) ? 1 : 0; }
+extern "C" int dsr_conv_dgrad_add(const dsr_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, void* dx,
+                                  dsr_stream_t s) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!dy || !w_dgrad || !addend || !dx) return dsr_fail(DSR_E_ARG, "conv_dgrad_add: null pointer");
+  if (!is_c64(d)) return dsr_fail(DSR_E_UNSUPPORTED, "conv_dgrad_add: 3x3 stride-1 zero-pad 64 -> 64 layers only");
+  launch_c64_dgrad(d, dy, w_dgrad, addend, dx, s);
+  return dsr_launch_status("dsr_conv_dgrad_add");
 }
 
 // ---- batched weight gradients: every 3x3 / stride-1 layer of a backward pass in one contraction launch + one reduction

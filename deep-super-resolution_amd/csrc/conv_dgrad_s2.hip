@@ -148,23 +148,34 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
             dma_issue(3, 0, cur ^ 1);
           }
         };
+        // 16 (k-half, pixel fragment) units as a software pipeline: the A fragment of unit u + 2 is requested before the
+        // MFMAs of unit u and the second k-half's weight fragments during the first half's last units (see the 8-wave loop
+        // of conv_gemm.hip: hipcc otherwise waits for every fragment right in front of its MFMAs)
+        const int slot0 = (g ^ sw) << 4, slot1 = ((4 + g) ^ sw) << 4;
+        U4 fb0[4], fb1[4], fa[3];
+        auto a_frag = [&](int u) { return *reinterpret_cast<const U4*>(pa + (u & 7) * 16 * 128 + (u < 8 ? slot0 : slot1)); };
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const int slot = ((4 * kk + g) ^ sw) << 4;
-          U4 fb[4];
+        for (int c = 0; c < 4; ++c)
+          if (s2_tap(c, s) >= 0) fb0[c] = *reinterpret_cast<const U4*>(pb + c * S2_BSLOT + slot0);
+        fa[0] = a_frag(0);
+        fa[1] = a_frag(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!late_dma) issue_next();
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (s2_tap(c, s) >= 0) fb[c] = *reinterpret_cast<const U4*>(pb + c * S2_BSLOT + slot);
-          if (kk == 0 && !late_dma) issue_next();
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const U4 fa = *reinterpret_cast<const U4*>(pa + i * 16 * 128 + slot);
+        for (int u = 0; u < 16; ++u) {
+          if (u + 2 < 16) fa[(u + 2) % 3] = a_frag(u + 2);
+          if (u == 5) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-              if (s2_tap(c, s) >= 0) acc[i][c] = mfma16<DT>(fb[c], fa, acc[i][c]);
+              if (s2_tap(c, s) >= 0) fb1[c] = *reinterpret_cast<const U4*>(pb + c * S2_BSLOT + slot1);
           }
-          if (kk == 0) {
-            __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (s2_tap(c, s) >= 0) acc[u & 7][c] = mfma16<DT>(u < 8 ? fb0[c] : fb1[c], fa[u % 3], acc[u & 7][c]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (u == 7) {
             if (late_dma) issue_next();
             __builtin_amdgcn_sched_barrier(0);
           }

@@ -301,21 +301,37 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 256 * 25
         const int cur = s & 1;
         const unsigned char* pa = sA + cur * A_STAGE + (wm * WM + r16) * 128;
         const unsigned char* pb = sB + cur * B_STAGE + (wn * WN + r16) * 128;
+        const int slot0 = (g ^ sw) << 4, slot1 = ((4 + g) ^ sw) << 4;
+        // The 2 * TM (A fragment, k-half) units of a step run as a software pipeline: the A fragment of unit u + 2 is
+        // requested before the TN MFMAs of unit u (three rolling registers sets), and the second k-half's B fragments during
+        // the first half's last units -- an LDS read then has 2 * TN MFMAs (128 cycles) to land.  Left to itself hipcc waits
+        // for each A fragment right before its MFMAs (`ds_read_b128; s_waitcnt lgkmcnt(0); 4 x v_mfma`): with two waves per
+        // SIMD that caps the MFMA pipe at ~2 * 64 / (64 + LDS latency).  The sched_barriers pin the order.
+        constexpr int NU = 2 * TM;
+        U4 fb0[TN], fb1[TN], fa[3];
+        auto a_frag = [&](int u) { return *reinterpret_cast<const U4*>(pa + (u % TM) * 16 * 128 + (u < TM ? slot0 : slot1)); };
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const int slot = ((4 * kk + g) ^ sw) << 4;
-          U4 fb[TN];
+        for (int k = 0; k < TN; ++k) fb0[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot0);
+        fa[0] = a_frag(0);
+        fa[1] = a_frag(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!late_dma && s + 1 < ks) dma_issue(nd, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int k = 0; k < TN; ++k) fb[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot);
-          if (kk == 0 && !late_dma && s + 1 < ks) dma_issue(nd, cur ^ 1);
+        for (int u = 0; u < NU; ++u) {
+          if (u + 2 < NU) fa[(u + 2) % 3] = a_frag(u + 2);
+          if (u == TM - 3) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const U4 fa = *reinterpret_cast<const U4*>(pa + i * 16 * 128 + slot);
-#pragma unroll
-            for (int k = 0; k < TN; ++k) acc[i][k] = SWAP ? mfma16<DT>(fb[k], fa, acc[i][k]) : mfma16<DT>(fa, fb[k], acc[i][k]);
+            for (int k = 0; k < TN; ++k) fb1[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot1);
           }
-          if (kk == 0) {
-            __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < TN; ++k) {
+            const U4& fbk = u < TM ? fb0[k] : fb1[k];
+            acc[u % TM][k] = SWAP ? mfma16<DT>(fbk, fa[u % 3], acc[u % TM][k]) : mfma16<DT>(fa[u % 3], fbk, acc[u % TM][k]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (u == TM - 1) {
             if (late_dma && s + 1 < ks) dma_issue(nd, cur ^ 1);
             if (s + 2 < ks) nd = decode_step(s + 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -477,7 +493,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 256 * 25
             if constexpr (ST) {
               const float vm = (rok && cok[j]) ? v : 0.f;   // statistics ignore tail rows / pad columns
               s1[j] += vm;
-              s2[j] += vm * vm;
+              s2[j] = __builtin_fmaf(vm, vm, s2[j]);        // (explicit: conv_gemm_big.hip must round identically)
             }
             o[j] = cok[j] ? actf(v) : 0.f;
           }
@@ -765,6 +781,7 @@ static void dispatch_dt(const ConvGemmArgs& a, hipStream_t st) {
 
 void dsr_launch_conv_gemm(const ConvGemmArgs& a, int dtype, hipStream_t st) {
   if (dsr_launch_conv_gemm_persist(a, dtype, st)) return;   // many-tile fast-path launches: persistent kernel
+  if (dsr_launch_conv_gemm_big(a, dtype, st)) return;       // 256x256 tiles, more tiles than CUs: persistent form
   if (dtype == DSR_DTYPE_BF16)
     dispatch_dt<DSR_DTYPE_BF16>(a, st);
   else

@@ -285,31 +285,38 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const WgradTileArgs& a, cons
     nxt = next_tile(nxt);
     if (t + 1 < t_end) dma(nxt, buf ^ 1);
     const unsigned char* st = smem + buf * STAGE;
+    // 18 (tile row, tap) units as a software pipeline: the X fragments of unit u + 2 (and the dY fragments of the second
+    // row, early) are requested before the 4 MFMAs of unit u; hipcc otherwise issues `4 reads; s_waitcnt lgkmcnt(0);
+    // 4 MFMAs` per tap.  Three rolling fragment sets (144 of the 256 registers are accumulators).
+    auto frag = [&](int off) {
+      const s16x4 lo = tr_read(st + off);
+      const s16x4 hi = tr_read(st + off + 2048);
+      return __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto load_b = [&](int u, U4* dst) {
+      const int r = u / 9, tp = u % 9, kh = tp / 3, kw = tp % 3;
+      dst[0] = frag(offB[kw][0] + ((r + kh) * HC + kw) * 128);
+      dst[1] = frag(offB[kw][1] + ((r + kh) * HC + kw) * 128);
+    };
+    U4 fa[2][2], fb[3][2];
+    fa[0][0] = frag(offA[0]);
+    fa[0][1] = frag(offA[1]);
+    load_b(0, fb[0]);
+    load_b(1, fb[1]);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      U4 fa[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const s16x4 lo = tr_read(st + offA[i] + r * 32 * 128);
-        const s16x4 hi = tr_read(st + offA[i] + r * 32 * 128 + 2048);
-        fa[i] = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    for (int u = 0; u < 9 * R; ++u) {
+      const int r = u / 9, tp = u % 9;
+      if (u + 2 < 9 * R) load_b(u + 2, fb[(u + 2) % 3]);
+      if (u == 5) {
+        fa[1][0] = frag(offA[0] + 32 * 128);
+        fa[1][1] = frag(offA[1] + 32 * 128);
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          U4 fb[2];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const s16x4 lo = tr_read(st + offB[kw][j] + ((r + kh) * HC + kw) * 128);
-            const s16x4 hi = tr_read(st + offB[kw][j] + ((r + kh) * HC + kw) * 128 + 2048);
-            fb[j] = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-          }
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[kh * 3 + kw][i][j] = mfma16<DT>(fa[i], fb[j], acc[kh * 3 + kw][i][j]);
-        }
+        for (int j = 0; j < 2; ++j) acc[tp][i][j] = mfma16<DT>(fa[r][i], fb[u % 3][j], acc[tp][i][j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -488,29 +495,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
     }
     if (t + 1 < t_end) dma(nxt, buf ^ 1);
     const unsigned char* st = smem + buf * STAGE;
-    U4 fa[2];
+    // the 9 taps as a software pipeline (see conv_wgrad_dma_body): X fragments of tap u + 2 requested before the MFMAs of tap u
+    U4 fa[2], fb[3][2];
+    auto load_b = [&](int u, U4* dst) {
+      const int kh = u / 3, kw = u % 3;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const s16x4 lo = tr_read(st + offB[kw >> 1][j] + (kh * HC + kw) * 128);
+        const s16x4 hi = tr_read(st + offB[kw >> 1][j] + (kh * HC + kw) * 128 + 32 * 128);
+        dst[j] = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+    };
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const s16x4 lo = tr_read(st + offA[i]);
       const s16x4 hi = tr_read(st + offA[i] + 2048);
       fa[i] = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
+    load_b(0, fb[0]);
+    load_b(1, fb[1]);
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    for (int u = 0; u < 9; ++u) {
+      if (u + 2 < 9) load_b(u + 2, fb[(u + 2) % 3]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        U4 fb[2];
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const s16x4 lo = tr_read(st + offB[kw >> 1][j] + (kh * HC + kw) * 128);
-          const s16x4 hi = tr_read(st + offB[kw >> 1][j] + (kh * HC + kw) * 128 + 32 * 128);
-          fb[j] = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[kh * 3 + kw][i][j] = mfma16<DT>(fa[i], fb[j], acc[kh * 3 + kw][i][j]);
-      }
+        for (int j = 0; j < 2; ++j) acc[u][i][j] = mfma16<DT>(fa[i], fb[u % 3][j], acc[u][i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   float* P = a.partial + (size_t)blockIdx.y * 9 * a.CoutP * a.CinP;

@@ -76,6 +76,7 @@ static inline bool dsr_conv_gemm_use_256(long long M, int NB, bool fast, bool st
 }
 
 bool dsr_launch_conv_gemm_persist(const ConvGemmArgs& a, int dtype, hipStream_t st);   // conv_gemm_persist.hip
+bool dsr_launch_conv_gemm_big(const ConvGemmArgs& a, int dtype, hipStream_t st);       // conv_gemm_big.hip
 
 struct WgradArgs {
   const void* x;    // [N][IH][IW][CinP]

@@ -256,15 +256,24 @@ class batched_wgrad:
                 g.copy_(alias)                            # autograd stored a copy made before the launch: refresh it
 
 
-def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape, weight=None):
+def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape, weight=None, addend=None):
+    """dx (+ `addend`: the gradient that reaches x along a skip path, summed in the dgrad epilogue where the kernel can) and dw."""
     lib = _lib.lib()
     dx = dw = None
     if need_dx:
         dx = torch.empty_like(x)
-        wsz = lib.dsr_conv_dgrad_workspace(C.byref(desc))
-        ws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=x.device)
-        check(_timed("dgrad", desc, lambda: lib.dsr_conv_dgrad(C.byref(desc), _ptr(dy), _ptr(wd), _ptr(dx), _ptr(ws), wsz,
-                                                                 _stream())))
+        if addend is not None and lib.dsr_conv_dgrad_add_supported(C.byref(desc)):
+            addend = addend.contiguous()
+            check(_timed("dgrad", desc, lambda: lib.dsr_conv_dgrad_add(C.byref(desc), _ptr(dy), _ptr(wd), _ptr(addend), _ptr(dx),
+                                                                         _stream()), name="conv_c64_kernel<2>"))
+            addend = None
+        else:
+            wsz = lib.dsr_conv_dgrad_workspace(C.byref(desc))
+            ws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=x.device)
+            check(_timed("dgrad", desc, lambda: lib.dsr_conv_dgrad(C.byref(desc), _ptr(dy), _ptr(wd), _ptr(dx), _ptr(ws), wsz,
+                                                                     _stream())))
+    if addend is not None:
+        dx = addend if dx is None else dx + addend
     if (need_dw and _wgrad_batch is not None and weight is not None and weight.grad is None
             and not getattr(weight, "_post_accumulate_grad_hooks", None)      # (a hook would read the gradient at once)
             and lib.dsr_conv_wgrad_batchable(C.byref(desc))):
@@ -484,7 +493,7 @@ class ConvBNAct(torch.autograd.Function):
                               None, _ptr(scale), _ptr(shift), _ptr(res))
                 check(_timed("fwd", desc, lambda: lib.dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y),
                                                                      _stream()), ep))
-                return y
+                return (y, x) if cfg.get("carry_input", False) else y
             ep = Epilogue(ACT_NONE, 0.0, None, _ptr(bias), None, 0, None)
             check(_timed("fwd", desc, lambda: lib.dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y),
                                                                  _stream()), ep))
@@ -500,10 +509,15 @@ class ConvBNAct(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, y, wd, scale, shift, mean, rstd,
                               prelu if prelu is not None else torch.empty(0, device=dev))
+        if cfg.get("carry_input", False):
+            # the input comes back as a second output: a residual block hands THAT to its skip connection, so both gradients
+            # of the block input arrive at this node and are summed in its dgrad epilogue (dsr_conv_dgrad_add) instead of by
+            # an elementwise pass of autograd's
+            return out, x
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dcarry=None):
         x, y, wd, scale, shift, mean, rstd, prelu = ctx.saved_tensors
         prelu = prelu if prelu.numel() else None
         lib = _lib.lib()
@@ -531,7 +545,7 @@ class ConvBNAct(torch.autograd.Function):
                                           _ptr(c1), _ptr(c2), _ptr(dy), p, cp, ctx.act, slope, _ptr(prelu),
                                           int(ctx.train), _stream()))
         dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape,
-                                 getattr(ctx, "weight_ref", None))
+                                 getattr(ctx, "weight_ref", None), dcarry)
         db = None
         if ctx.has_bias and not ctx.train:
             # a bias in front of a train-mode BatchNorm has an analytically zero gradient (the reference holds ~1e-9

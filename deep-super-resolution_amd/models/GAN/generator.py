@@ -34,14 +34,16 @@ class ResidualBlock(nn.Module):
         self.compute_dtype = torch.bfloat16
 
     def _block(self, x, bn_updates=1):
-        cfg1 = dict(stride=1, pad=1, act=F.ACT_PRELU, train=self.training, bn_updates=bn_updates)
-        z = F.ConvBNAct.apply(x, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias,
-                              self.bn1.running_mean, self.bn1.running_var, self.bn1.num_batches_tracked,
-                              self.prelu1.weight, None, cfg1)                         # generator.py:15-18
+        # carry_input: conv1's node hands the block input back for the skip connection, so that the two gradients of x
+        # (conv path, skip path) meet inside its input-gradient launch instead of in an elementwise add
+        cfg1 = dict(stride=1, pad=1, act=F.ACT_PRELU, train=self.training, bn_updates=bn_updates, carry_input=True)
+        z, skip = F.ConvBNAct.apply(x, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias,
+                                    self.bn1.running_mean, self.bn1.running_var, self.bn1.num_batches_tracked,
+                                    self.prelu1.weight, None, cfg1)                   # generator.py:15-18
         cfg2 = dict(stride=1, pad=1, act=F.ACT_NONE, train=self.training, bn_updates=bn_updates)
         return F.ConvBNAct.apply(z, self.conv2.weight, self.conv2.bias, self.bn2.weight, self.bn2.bias,
                                  self.bn2.running_mean, self.bn2.running_var, self.bn2.num_batches_tracked,
-                                 None, x, cfg2)                                       # :20-23 (x + z fused)
+                                 None, skip, cfg2)                                    # :20-23 (x + z fused)
 
     def forward(self, x):
         if _is_internal(x):

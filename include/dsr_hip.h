@@ -106,6 +106,11 @@ int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const void* dout, 
 /* Which kernel the dispatcher launches for this descriptor (measurement aid: bench.py labels its HIP-event timings
  * with it so they can be matched against rocprofv3's kernel names).  op: 0 forward, 1 dgrad, 2 wgrad.  `e` may be
  * NULL (no statistics, no pixel shuffle, NHWC output).  Returns a static string; never NULL. */
+/* dx = dgrad(dy) + addend in one launch (the gradient of a residual block's input: conv path + skip path,
+ * generator.py:24); dsr_conv_dgrad_add_supported tells whether the shape is taken (64 -> 64 3x3 stride 1 zero pad). */
+int dsr_conv_dgrad_add_supported(const dsr_conv_desc* d);
+int dsr_conv_dgrad_add(const dsr_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, void* dx,
+                       dsr_stream_t s);
 /* Every 3x3 / stride-1 / pad-1 weight gradient of a backward pass in one contraction launch + one reduction launch
  * (replaces the per-layer weight-gradient kernels of loss.backward(), train_GAN.py:52,63).  Entries whose dws[i] are equal
  * must be adjacent and are summed into that one gradient (a weight applied to two batches).  All entries share one dtype.

@@ -227,7 +227,14 @@ def c3_oracle(c3_states):
     with lowp.storage(torch.bfloat16):
         recipes.gan_step(st, lr, hr, capture=sim_cap)
     del st
-    return vsd, lr, hr, sim_cap
+    # ... and the fp32 oracle's two steps themselves (deterministic; both stream forms of the HIP step are compared with them)
+    st = recipes.GanState({k: v.clone() for k, v in gsd.items()}, {k: v.clone() for k, v in dsd.items()}, vsd, lr=1e-4)
+    ref_steps = []
+    for _ in range(2):
+        cap = {}
+        rld, rlg, rfake = recipes.gan_step(st, lr, hr, capture=cap)
+        ref_steps.append((rld, rlg, rfake, {k: cap[k] for k in ("g_grads", "d_grads")} if not ref_steps else None))
+    return vsd, lr, hr, sim_cap, ref_steps, st
 
 
 @pytest.mark.parametrize("overlap", [True, False])
@@ -242,20 +249,18 @@ def test_config3_gan_step_full_spatial_size(dev, c3_states, c3_oracle, overlap):
                                   P("steps"))
     n, s, f = 2, 128, 4
     gsd, dsd = c3_states
-    vsd, lr, hr, sim_cap = c3_oracle
+    vsd, lr, hr, sim_cap, ref_steps, st = c3_oracle
     g, d = Gm.Generator(f, 16), Dm.Discriminator((s * f, s * f))
     g.load_state_dict(gsd), d.load_state_dict(dsd)
     g.to(dev).train(), d.to(dev).train()
     perc = GANu.PerceptualLoss().to(dev)
     og, od = optim.FusedAdam(g.parameters(), lr=1e-4), optim.FusedAdam(d.parameters(), lr=1e-4)
-    st = recipes.GanState({k: v.clone() for k, v in gsd.items()}, {k: v.clone() for k, v in dsd.items()}, vsd, lr=1e-4)
     lrd, hrd = lr.to(dev), hr.to(dev)
     rec = {}
     for it in range(2):
-        cap = {}
         ld, lg, fake = steps.gan_step(g, d, perc, og, od, lrd, hrd, overlap=overlap)
         torch.cuda.synchronize()
-        rld, rlg, rfake = recipes.gan_step(st, lr, hr, capture=cap)
+        rld, rlg, rfake, cap = ref_steps[it]
         dp = abs(losses.psnr(fake.cpu(), hr) - losses.psnr(rfake, hr))
         rec[f"step{it}"] = dict(loss_d=(ld.item(), rld), loss_g=(lg.item(), rlg), dpsnr_db=dp,
                                 psnr_hip_vs_oracle_db=losses.psnr(fake.cpu(), rfake))

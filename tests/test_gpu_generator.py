@@ -199,3 +199,35 @@ def test_graphed_step_equals_eager(dev):
     assert torch.equal(loss_e, loss_g)
     for (k, a), (_, b) in zip(g_e.state_dict().items(), g_g.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_residual_skip_gradient_fused_equals_autograd_sum(dev):
+    """ResidualBlock hands its input to the skip connection through conv1's autograd node (carry_input), whose input-gradient
+    launch then adds the skip path's gradient (dsr_conv_dgrad_add).  Against the same block with the skip taken from x directly
+    (autograd sums the two gradients with an elementwise add): identical arithmetic => every gradient bit for bit."""
+    Gm, F = P("models.GAN.generator"), P("functional")
+    torch.manual_seed(3)
+    blk = Gm.ResidualBlock().to(dev).train()
+    x0 = (torch.rand(2, 24, 40, 64) - 0.5).to(torch.bfloat16).to(dev)
+    go = (torch.rand(2, 24, 40, 64) - 0.5).to(torch.bfloat16).to(dev)
+
+    def unfused(x):
+        cfg1 = dict(stride=1, pad=1, act=F.ACT_PRELU, train=True, bn_updates=0)
+        z = F.ConvBNAct.apply(x, blk.conv1.weight, blk.conv1.bias, blk.bn1.weight, blk.bn1.bias, blk.bn1.running_mean,
+                              blk.bn1.running_var, blk.bn1.num_batches_tracked, blk.prelu1.weight, None, cfg1)
+        cfg2 = dict(stride=1, pad=1, act=F.ACT_NONE, train=True, bn_updates=0)
+        return F.ConvBNAct.apply(z, blk.conv2.weight, blk.conv2.bias, blk.bn2.weight, blk.bn2.bias, blk.bn2.running_mean,
+                                 blk.bn2.running_var, blk.bn2.num_batches_tracked, None, x, cfg2)
+
+    res = []
+    for fn in (unfused, lambda x: blk._block(x, 0)):
+        for p in blk.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        out = fn(x)
+        out.backward(go)
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in blk.parameters() if p.grad is not None]))
+    (o_a, gx_a, gp_a), (o_b, gx_b, gp_b) = res
+    assert torch.equal(o_a, o_b) and torch.equal(gx_a, gx_b)
+    assert len(gp_a) == len(gp_b) and all(torch.equal(a, b) for a, b in zip(gp_a, gp_b))

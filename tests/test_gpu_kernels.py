@@ -637,3 +637,90 @@ def test_conv_wgrad_batched_equals_per_layer_launches(dev):
         scale = float(ref.abs().max())
         assert float((got - ref).abs().max()) < 2e-5 * scale + 1e-4, i          # fp32 accumulation of exact bf16 products
         assert float((got - per_layer.cpu().double()).abs().max()) < 2e-5 * scale + 1e-4, i
+
+
+@pytest.mark.parametrize("op", ["fwd", "fwd_stats", "dgrad"])
+def test_conv_256x256_persistent_equals_one_tile_per_block(dev, op):
+    """conv_gemm_big_kernel (the 256x256 tile as persistent blocks that start the next tile's DMA before their output stores;
+    conv_gemm_big.hip) against conv_gemm_kernel<256x256> on a launch with 640 tiles on 256 CUs (2.5 tiles per block: blocks with
+    two and with three tiles, both LDS stages in the C-staging role): same K order and the same epilogue arithmetic => outputs
+    bit for bit, statistics to 1e-6.  The persistent form is an opt-in experiment (DSR_CONV_BIG_PERSIST=1; measured slower)."""
+    import ctypes as C
+    import os
+    L = P("_lib")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n, h, w, cin, cout = 5, 128, 128, 64, 512            # M = 81,920 = 320 x 256; two column tiles
+    if op == "dgrad":
+        cin, cout = 512, 64
+    d = L.ConvDesc(L.BF16, n, h, w, cin, cout, 3, 3, 1, 1, 0)
+    g = torch.Generator(device="cpu").manual_seed(17)
+    wt = ((torch.rand(cout, cin, 3, 3, generator=g) - 0.5) * 0.1).to(dev)
+    wf = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 0), dtype=torch.bfloat16, device=dev)
+    wd = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 1), dtype=torch.bfloat16, device=dev)
+    L.check(lib.dsr_conv_pack_weight(C.byref(d), wt.data_ptr(), wf.data_ptr(), wd.data_ptr(), st))
+    x = (torch.rand(n, h, w, cin, generator=g) - 0.5).to(torch.bfloat16).to(dev)
+    dy = (torch.rand(n, h, w, cout, generator=g) - 0.5).to(torch.bfloat16).to(dev)
+    bias = (torch.rand(cout, generator=g) - 0.5).to(dev)
+    outs, stats = [], []
+    old = os.environ.get("DSR_CONV_BIG_PERSIST")
+    try:
+        for mode in ("0", "1"):
+            os.environ["DSR_CONV_BIG_PERSIST"] = mode
+            if op != "dgrad":
+                y = torch.full((n, h, w, cout), float("nan"), dtype=torch.bfloat16, device=dev)
+                rows = lib.dsr_conv_stats_rows(C.byref(d))
+                part = torch.full(((rows + 64) * 2 * cout,), float("nan"), dtype=torch.float32, device=dev)
+                ep = L.Epilogue(L.ACT_LEAKY if op == "fwd" else L.ACT_NONE, 0.2, None, bias.data_ptr(),
+                                part.data_ptr() if op == "fwd_stats" else None, 0, None)
+                assert "256x256" in lib.dsr_conv_kernel_name(C.byref(d), 0, C.byref(ep)).decode()
+                L.check(lib.dsr_conv_fwd(C.byref(d), x.data_ptr(), wf.data_ptr(), C.byref(ep), y.data_ptr(), st))
+                outs.append(y)
+                if op == "fwd_stats":
+                    stats.append(part[:rows * 2 * cout].clone())
+            else:
+                dx = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
+                assert "256x256" in lib.dsr_conv_kernel_name(C.byref(d), 1, None).decode()
+                L.check(lib.dsr_conv_dgrad(C.byref(d), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), None, 0, st))
+                outs.append(dx)
+    finally:
+        if old is None:
+            os.environ.pop("DSR_CONV_BIG_PERSIST", None)
+        else:
+            os.environ["DSR_CONV_BIG_PERSIST"] = old
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[0], outs[1])
+    if stats:      # (the persistent kernel sums a tile's statistics in two passes of 64 rows: same values, another order)
+        assert torch.isfinite(stats[1]).all()
+        assert float((stats[0].double() - stats[1].double()).abs().max() / stats[0].double().abs().max()) < 1e-6
+
+
+def test_conv_dgrad_add_equals_dgrad_then_add(dev):
+    """dsr_conv_dgrad_add (64 -> 64 3x3 input gradient with the skip path's gradient added in the epilogue; the residual blocks
+    of generator.py:4-25) against dsr_conv_dgrad followed by a bf16 add: both round the conv sum to bf16, add in fp32 and round
+    again => BIT FOR BIT equal, ragged tiles included; other shapes are refused."""
+    import ctypes as C
+    L = P("_lib")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n, h, w = 3, 37, 70
+    d = L.ConvDesc(L.BF16, n, h, w, 64, 64, 3, 3, 1, 1, 0)
+    assert lib.dsr_conv_dgrad_add_supported(C.byref(d)) == 1
+    assert lib.dsr_conv_dgrad_add_supported(C.byref(L.ConvDesc(L.BF16, n, h, w, 64, 128, 3, 3, 1, 1, 0))) == 0
+    g = torch.Generator(device="cpu").manual_seed(23)
+    wt = ((torch.rand(64, 64, 3, 3, generator=g) - 0.5) * 0.2).to(dev)
+    wf = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 0), dtype=torch.bfloat16, device=dev)
+    wd = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 1), dtype=torch.bfloat16, device=dev)
+    L.check(lib.dsr_conv_pack_weight(C.byref(d), wt.data_ptr(), wf.data_ptr(), wd.data_ptr(), st))
+    dy = (torch.rand(n, h, w, 64, generator=g) - 0.5).to(torch.bfloat16).to(dev)
+    add = (torch.rand(n, h, w, 64, generator=g) - 0.5).to(torch.bfloat16).to(dev)
+    dx0 = torch.empty_like(dy)
+    L.check(lib.dsr_conv_dgrad(C.byref(d), dy.data_ptr(), wd.data_ptr(), dx0.data_ptr(), None, 0, st))
+    ref = dx0 + add
+    dx1 = torch.full_like(dy, float("nan"))
+    L.check(lib.dsr_conv_dgrad_add(C.byref(d), dy.data_ptr(), wd.data_ptr(), add.data_ptr(), dx1.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert torch.isfinite(dx1.float()).all() and torch.equal(ref, dx1)
+    bad = L.ConvDesc(L.BF16, n, h, w, 64, 128, 3, 3, 1, 1, 0)
+    assert lib.dsr_conv_dgrad_add(C.byref(bad), dy.data_ptr(), wd.data_ptr(), add.data_ptr(), dx1.data_ptr(), st) < 0

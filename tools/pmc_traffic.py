@@ -18,7 +18,7 @@ def family(name):
         return f"conv_c64_kernel<{m.group(1)}>"            # same labels as dsr_conv_kernel_name()
     if "conv_wgrad_tile_kernel" in name:
         return "conv_wgrad_tile_kernel<1x1>"
-    for k in ("conv_wgrad_dma_s2_kernel", "conv_wgrad_dma_kernel", "conv_smalln_kernel", "conv_wgrad_taps_kernel", "conv_wgrad_kernel"):
+    for k in ("conv_wgrad_dma_batch_kernel", "conv_wgrad_dma_s2_kernel", "conv_wgrad_dma_kernel", "conv_smalln_kernel", "conv_wgrad_taps_kernel", "conv_wgrad_kernel"):
         if k in name:
             return k
     return re.sub(r"<.*", "", name.split("(")[0]).strip()
