@@ -265,7 +265,7 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape, weight=None,
         if addend is not None and lib.dsr_conv_dgrad_add_supported(C.byref(desc)):
             addend = addend.contiguous()
             check(_timed("dgrad", desc, lambda: lib.dsr_conv_dgrad_add(C.byref(desc), _ptr(dy), _ptr(wd), _ptr(addend), _ptr(dx),
-                                                                         _stream()), name="conv_c64_kernel<2>"))
+                                                                         _stream()), name="conv_c64_kernel<3>"))
             addend = None
         else:
             wsz = lib.dsr_conv_dgrad_workspace(C.byref(desc))
