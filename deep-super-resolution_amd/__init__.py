@@ -12,10 +12,11 @@ import types
 __all__ = ["install_dropin", "load"]
 
 # reference module path -> the mirror in this package.  Only LEAF modules are aliased: the reference's own `utils` and
-# `models` packages keep serving everything this package does not mirror (utils.common, utils.degradation, dataset.py's
-# imports), so `from utils.common import *` (train_GAN.py:15, eval_GAN.py:14, DIP.py:15) keeps working.
+# `models` packages keep serving everything this package does not mirror (utils.common), so `from utils.common import *`
+# (train_GAN.py:15, eval_GAN.py:14, DIP.py:15) keeps working.  `dataset` is a top-level module of the reference.
 MIRRORS = ("models.GAN.generator", "models.GAN.discriminator", "models.DIP", "models.DIP.skip", "models.DIP.utils",
-           "utils.downsampler", "utils.GAN", "utils.DIP")
+           "utils.downsampler", "utils.GAN", "utils.DIP", "utils.degradation")
+TOP_LEVEL_MIRRORS = ("dataset",)
 
 
 def load(sub):
@@ -58,14 +59,17 @@ def install_dropin():
         sys.modules[name] = ours
         setattr(parent, leaf, ours)      # `import utils.GAN as g` / `from utils import GAN` read the attribute
         done.append(name)
+    for name in TOP_LEVEL_MIRRORS:       # dataset.py (its own version needs torchvision, which is absent here)
+        sys.modules[name] = load(name)
+        done.append(name)
     try:                                 # utils/DIP.py:3 -- the reference's helpers ride along when they exist
         common = importlib.import_module("utils.common")
     except ImportError:
         common = None
-    if common is not None:
-        dip = sys.modules["utils.DIP"]
+    if common is not None:               # (utils/degradation.py:2 does the same `from utils.common import *`)
         public = getattr(common, "__all__", [k for k in vars(common) if not k.startswith("_")])
-        for k in public:
-            if not hasattr(dip, k):
-                setattr(dip, k, getattr(common, k))
+        for mod in (sys.modules["utils.DIP"], sys.modules["utils.degradation"]):
+            for k in public:
+                if not hasattr(mod, k):
+                    setattr(mod, k, getattr(common, k))
     return done

@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 SOURCES = ["conv_gemm.hip", "conv_gemm_persist.hip", "conv_gemm_big.hip", "conv_wgrad.hip", "conv_wgrad_tile.hip", "conv_smalln.hip",
            "conv_c64.hip", "conv_cin8.hip", "conv_dgrad_s2.hip", "conv_first_bwd.hip", "conv_api.hip", "pointwise.hip", "linear.hip",
-           "resample.hip", "metrics.hip"]
+           "resample.hip", "metrics.hip", "data.hip"]
 SO = os.path.join(CSRC, "libdsr_hip.so")
 # -Werror=return-type: a C-ABI entry point that flows off its end without `return` is undefined behaviour (hipcc -O3
 # emits no `ret`, the call runs into the next function) -- that was the round-1 host segfault in dsr_pw_bn_eval_affine.

@@ -256,6 +256,31 @@ int dsr_ssim_blocks(int planes, int H, int W);
 int dsr_ssim_f32(const float* img1, const float* img2, int planes, int H, int W, float data_range, float* partial,
                  dsr_stream_t s);
 
+/* ---- data-side byte kernels (dataset.py:9-62,121-159; utils/degradation.py:5-20) on device-resident
+ * uint8 HWC images.  Integer / byte arithmetic, bit-identical to Pillow / numpy.
+ * dsr_resample_u8: ONE pass of Pillow's 8-bit resampler along `axis` (1 = width, 0 = height); `bounds` [out_size][2] and `kk`
+ * [out_size][ksize] are the 22-bit fixed-point tables of Pillow's precompute_coeffs + normalize_coeffs_8bpc (device int32,
+ * built on the host by utils/degradation.py: resample_tables).  Image.resize(.., BICUBIC) = width pass, then height pass. */
+int dsr_resample_u8(const unsigned char* src, unsigned char* dst, int H, int W, int C, int axis, int out_size, const int* bounds,
+                    const int* kk, int ksize, dsr_stream_t s);
+/* out = uint8(clip(img + noise, 0, 255)) (truncating cast); noise float64 (drawn by numpy, as the reference does) or float32 */
+int dsr_noise_gaussian_u8(const unsigned char* img, const void* noise, int noise_is_f64, unsigned char* out, size_t n, dsr_stream_t s);
+/* salt -> 255, then pepper -> 0, per pixel over all channels; salt / pepper: [H][W] bytes (non-zero = hit) */
+int dsr_salt_pepper_u8(const unsigned char* img, const unsigned char* salt, const unsigned char* pepper, unsigned char* out, int H,
+                       int W, int C, dsr_stream_t s);
+/* B patches of ph x pw pixels, one from each of B RGB images (HOST tables of device pointers / sizes / corners), converted to an
+ * fp32 [B][3][ph][pw] batch: ToTensor (/255) followed by the scaling `mode` selects */
+enum { DSR_PATCH_UNIT = 0,      /* [0,1]: ToTensor only */
+       DSR_PATCH_LR_REF = 1,    /* dataset.py:152: /255 a second time (the reference's LR scaling as written) */
+       DSR_PATCH_HR_REF = 2,    /* dataset.py:155-157: /255 a second time, *2, -1 (as written) */
+       DSR_PATCH_HR_UNIT = 3 }; /* *2 - 1: the [-1,1] its comments intend */
+/* dataset.py:149-159 in place on an fp32 tensor ToTensor already put in [0,1]: mode DSR_PATCH_LR_REF: x /= 255;
+ * DSR_PATCH_HR_REF: x = x / 255 * 2 - 1 (true divisions, as on the host) */
+int dsr_scale_images_f32(float* x, size_t n, int mode, dsr_stream_t s);
+#define DSR_PATCH_BATCH_MAX 64
+int dsr_patch_batch_u8(int count, const unsigned char* const* images, const int* heights, const int* widths, const int* tops,
+                       const int* lefts, int ph, int pw, int mode, float* out, dsr_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,6 +120,17 @@ def test_bad_arguments_return_codes_not_crashes(so):
         lambda: lib.dsr_linear_dgrad(0, N, N, N, 4, 8, 64, st),
         lambda: lib.dsr_linear_wgrad(0, N, N, N, 32, 8, 64, st),
         lambda: lib.dsr_linear_wgrad_gathered(0, N, N, N, 32, 8, 64, 2, 0.5, st),
+        lambda: lib.dsr_resample_u8(N, N, 4, 4, 3, 1, 2, N, N, 5, st),
+        lambda: lib.dsr_resample_u8(one, one, 4, 4, 3, 2, 2, one, one, 5, st),                # axis
+        lambda: lib.dsr_noise_gaussian_u8(N, N, 1, N, 16, st),
+        lambda: lib.dsr_salt_pepper_u8(N, N, N, N, 4, 4, 3, st),
+        lambda: lib.dsr_scale_images_f32(N, 16, 1, st),
+        lambda: lib.dsr_scale_images_f32(one, 16, 0, st),                                      # mode
+        lambda: lib.dsr_patch_batch_u8(1, None, None, None, None, None, 4, 4, 0, N, st),
+        lambda: lib.dsr_patch_batch_u8(1, (ctypes.c_void_p * 1)(16), (ctypes.c_int * 1)(4), (ctypes.c_int * 1)(4), (ctypes.c_int * 1)(2),
+                                       (ctypes.c_int * 1)(0), 4, 4, 0, one, st),               # rows 2..5 of a 4-row image
+        lambda: lib.dsr_patch_batch_u8(1, (ctypes.c_void_p * 1)(16), (ctypes.c_int * 1)(4), (ctypes.c_int * 1)(4), (ctypes.c_int * 1)(0),
+                                       (ctypes.c_int * 1)(0), 4, 4, 9, one, st),               # mode
         lambda: lib.dsr_conv_wgrad_batched(1, None, None, None, None, N, 0, st),
         lambda: lib.dsr_conv_wgrad_batched(0, ctypes.byref(d), None, None, None, N, 0, st),
         lambda: lib.dsr_conv_wgrad_batched(100000, ctypes.byref(d), None, None, None, N, 0, st),

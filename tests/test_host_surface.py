@@ -35,8 +35,8 @@ def run_py(code, with_ref):
 @needs_ref
 def test_install_dropin_keeps_reference_packages():
     """with the reference on sys.path, the lines of train_GAN.py:11-15 / DIP.py:11-15 / eval_GAN.py:11-14
-    must all resolve: mirrored leaves to this package, everything else (utils.common, utils.degradation) to the
-    reference's own modules."""
+    must all resolve: mirrored leaves to this package (since round 2 that includes utils.degradation and the top-level
+    dataset module, whose own version needs torchvision), everything else (utils.common) to the reference's own modules."""
     out = run_py("""
         pk = importlib.import_module("deep-super-resolution_amd")
         names = pk.install_dropin()
@@ -49,7 +49,10 @@ def test_install_dropin_keeps_reference_packages():
         from utils.DIP import *
         import utils.common, utils.degradation, utils.DIP, models.DIP.skip, models.GAN.generator as gg
         assert utils.common.__file__.startswith("/root/reference/"), utils.common.__file__
-        assert utils.degradation.__file__.startswith("/root/reference/")
+        assert utils.degradation.__name__ == "deep-super-resolution_amd.utils.degradation"
+        from dataset import GANDIV2KDataset, DIV2KDataset, get_image_pair          # (train_GAN.py:12 `from dataset import *`)
+        assert GANDIV2KDataset.__module__ == "deep-super-resolution_amd.dataset"
+        assert callable(utils.degradation.downsample) and utils.degradation.save_model is utils.common.save_model
         for obj in (Generator, Discriminator, Downsampler, get_net, PerceptualLoss, get_loss_D, optimize, get_noise):
             assert obj.__module__.startswith("deep-super-resolution_amd."), (obj, obj.__module__)
         assert gg.__name__ == "deep-super-resolution_amd.models.GAN.generator"
@@ -60,7 +63,7 @@ def test_install_dropin_keeps_reference_packages():
         assert type(g).__module__.startswith("deep-super-resolution_amd.")
         print("OK", len(names))
     """, with_ref=True)
-    assert out.startswith("OK 8")
+    assert out.startswith("OK 10")
 
 
 def test_install_dropin_standalone():

@@ -288,3 +288,61 @@ def test_ssim_restatement_properties():
     s1, s2 = metrics.ssim(a, a + n1), metrics.ssim(a, a + 3 * n1)
     assert 0.0 < s2 < s1 < 1.0
     assert abs(metrics.ssim(a + n1, a) - s1) < 1e-12
+
+
+# ----------------------------------------------------------------------------- the data-side arithmetic
+def test_data_degradation_matches_reference_functions(golden):
+    """oracle/data.py against what the reference's own utils/degradation.py (Pillow bicubic ``downsample``, numpy noise) and
+    the direct Pillow call of dataset.py:45 produced (tests/golden/make_golden.py gen_data): all uint8, bit for bit.  The
+    noise draws are repeated here from numpy's global generator with the seeds and the draw order of the reference."""
+    from oracle import data as od
+    z = golden("data_degradation")
+    img = od.sample_image("in:data_a", 90, 124)
+    d2 = od.downsample(img, 2)
+    d4 = od.downsample(d2, 2)
+    assert np.array_equal(d2, z["down2"]) and np.array_equal(d4, z["down4"])
+    assert np.array_equal(od.downsample(img, 3), z["down3"])
+    assert np.array_equal(od.resize_u8(img, 4 * d4.shape[1], 4 * d4.shape[0]), z["hr_resized"])
+    assert np.array_equal(od.resize_u8(od.sample_image("in:data_b", 71, 53), 37, 50), z["odd_resized"])
+    np.random.seed(7)
+    noise = np.random.normal(scale=0.1 * 255, size=d2.shape)                       # utils/degradation.py:6
+    assert np.array_equal(od.add_gaussian_noise(d2, noise), z["gauss"])
+    np.random.seed(8)
+    salt = np.random.rand(d2.shape[0], d2.shape[1]) < 0.02                        # :11
+    pepper = np.random.rand(d2.shape[0], d2.shape[1]) < 0.03                      # :12
+    assert np.array_equal(od.add_salt_pepper(d2, salt, pepper), z["salt_pepper"])
+
+
+def test_data_resize_matches_pillow_live():
+    """The same restatement against the Pillow installed beside the tests (same image here and on the GPU box): random and
+    smooth images, up- and down-scaling, odd sizes."""
+    PIL = pytest.importorskip("PIL.Image")
+    from oracle import data as od
+    rng = np.random.RandomState(0)
+    for h, w, ow, oh in [(64, 96, 48, 32), (37, 53, 18, 26), (100, 77, 77, 50), (50, 60, 100, 120), (45, 80, 31, 80)]:
+        img = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.array(PIL.fromarray(img).resize((ow, oh), PIL.BICUBIC))
+        assert np.array_equal(od.resize_u8(img, ow, oh), ref), (h, w, ow, oh)
+
+
+def test_data_scaling_and_patches():
+    """to_tensor / scale_images / train_patch_coords against the reference's expressions evaluated literally with torch and
+    numpy (dataset.py:121-159; dataset.py itself needs torchvision, which is absent here)."""
+    from oracle import data as od
+    img_lr = od.sample_image("in:data_lr", 24, 40)
+    img_hr = od.sample_image("in:data_hr", 96, 160)
+    lr_t = torch.from_numpy(img_lr).permute(2, 0, 1).contiguous().float().div(255)       # ToTensor
+    hr_t = torch.from_numpy(img_hr).permute(2, 0, 1).contiguous().float().div(255)
+    lr_t /= 255.0                                                                         # dataset.py:152
+    hr_t /= 255.0                                                                         # :155
+    hr_t *= 2                                                                             # :156
+    hr_t -= 1                                                                             # :157
+    lr_o, hr_o = od.scale_images(od.to_tensor(img_lr), od.to_tensor(img_hr))
+    assert np.array_equal(lr_o, lr_t.numpy()) and np.array_equal(hr_o, hr_t.numpy())
+    rng_a, rng_b = np.random.RandomState(5), np.random.RandomState(5)
+    for _ in range(20):
+        top, left, htop, hleft = od.train_patch_coords(24, 40, 16, 8, 4, rng_a)
+        cx = rng_b.randint(16 // 2, 40 - 16 // 2)                                         # :128
+        cy = rng_b.randint(8 // 2, 24 - 8 // 2)                                           # :129
+        assert (top, left) == (int(cy - 8 // 2), int(cx - 16 // 2)) and (htop, hleft) == (top * 4, left * 4)
+        assert 0 <= top and top + 8 <= 24 and 0 <= left and left + 16 <= 40
