@@ -266,7 +266,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int tiles,
 // in a fixed order through LDS, so the result does not depend on timing.  Replaces compact_rows + the serial finalize
 // (two launches and a boundary) wherever the producers emit few rows: the persistent c64 kernel (one row per block),
 // and the small problems (config 2, DIP).
-#define DSR_FINALIZE_PAR_ROWS 512      // measured (tools/_bin/fin_probe.py): one launch wins up to ~512 rows (6.6 us vs ~10 us for
+#define DSR_FINALIZE_PAR_ROWS 512      // measured (a sweep over the row count): one launch wins up to ~512 rows (6.6 us vs ~10 us for
                                        // compaction + finalize); at 2048 rows its latency chain loses (18.6 us vs 8 us)
 #define DSR_FINALIZE_PAR_ROWS_BWD 64   // three slices per row: loses from 512 rows on (36.7 us)
 template <int NS>
