@@ -27,6 +27,7 @@ Extra legs (rank 0, N = 1 only; each can be switched off):
 """
 import argparse
 import importlib
+import ctypes
 import json
 import os
 import socket
@@ -502,12 +503,22 @@ def main():
     for sy in syncs:
         sy.timing = world > 1 or force
     note("timed region")
+    # two (shader-clock cycles, 100 MHz ticks) samples bracket the timed steps on the stream: the clock the chip actually held
+    clk = torch.zeros(32, dtype=torch.int64, device=dev)
+    L = P("_lib")
+    st_ptr = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     t0 = time.perf_counter()
+    L.check(L.lib().dsr_clock_sample(ctypes.c_void_p(clk.data_ptr()), st_ptr))
     for _ in range(a.steps):
         step()
+    L.check(L.lib().dsr_clock_sample(ctypes.c_void_p(clk.data_ptr() + 128), st_ptr))
     t_issue = time.perf_counter() - t0          # host time to ISSUE the steps (GPU still running): launch-bound if ~ dt
     fence()
     dt = time.perf_counter() - t0
+    c = clk.cpu().tolist()
+    per_xcd = [(c[16 + 2 * x] - c[2 * x]) / (c[17 + 2 * x] - c[1 + 2 * x]) * 0.1            # cycles per 10 ns tick
+               for x in range(8) if c[1 + 2 * x] and c[17 + 2 * x] > c[1 + 2 * x]]
+    shader_ghz = sum(per_xcd) / len(per_xcd) if per_xcd else 0.0
     wait_ms = sum(sy.pop_wait_ms() for sy in syncs) / a.steps
     for sy in syncs:
         sy.timing = False
@@ -547,7 +558,10 @@ def main():
            "config": {"workload": a.workload + ": " + WORKLOADS[a.workload]["desc"],
                       "global_batch": WORKLOADS[a.workload]["batch"] * world, "parallelism": f"dp{world}"},
            "host_issue_ms_per_step": t_issue / a.steps * 1e3,
-           "hip_graph": bool(isinstance(step, _Callable))}
+           "hip_graph": bool(isinstance(step, _Callable)),
+           # average shader clock over the timed steps (s_memtime / s_memrealtime): the chip lowers it under load, so a
+           # fraction of the 2.5 PFLOP/s nominal peak (2.4 GHz) is really measured against peak * clock / 2.4
+           "avg_shader_clock_ghz": round(shader_ghz, 3)}
     if world > 1 or force:
         out["collective_wait_ms_per_step"] = wait_all
 

@@ -40,6 +40,7 @@ SIGNATURES = {
     "dsr_conv_wgrad_batched_workspace": (_Z, [_I, _DESC, C.POINTER(C.c_void_p)]),
     "dsr_conv_wgrad_batched": (_I, [_I, _DESC, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, _Z, _P]),
     "dsr_conv_kernel_name": (C.c_char_p, [_DESC, _I, C.POINTER(Epilogue)]),
+    "dsr_clock_sample": (_I, [_P, _P]),
     "dsr_resample_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "dsr_noise_gaussian_u8": (_I, [_P, _P, _I, _P, _Z, _P]),
     "dsr_salt_pepper_u8": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

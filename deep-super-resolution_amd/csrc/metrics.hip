@@ -97,3 +97,21 @@ extern "C" int dsr_ssim_f32(const float* img1, const float* img2, int planes, in
                      win, partial);
   return dsr_launch_status("dsr_ssim_f32");
 }
+
+// ---- measurement aid: (shader-clock cycles, 100 MHz real-time ticks) pairs, one per XCD.  Two samples around a region give
+// the clock the chip actually held there: MI355X lowers its shader clock under load (tools/clock_probe.hip: a register-only
+// MFMA loop on every CU runs at 1.22-1.28 GHz, not 2.4), which is what a fraction "of the 2.5 PFLOP/s peak" is really
+// measured against.  s_memtime counters of different XCDs are not synchronised with each other, so every block files its
+// pair under its own XCD (HW_REG_XCC_ID) and the host differences samples of the SAME XCD only.
+__global__ void clock_sample_kernel(unsigned long long* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 7u;
+    out[2 * xcc] = __builtin_amdgcn_s_memtime();
+    out[2 * xcc + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+extern "C" int dsr_clock_sample(unsigned long long* out16, dsr_stream_t st) {
+  DSR_REQUIRE(out16, "clock_sample: null pointer");
+  hipLaunchKernelGGL(clock_sample_kernel, dim3(64), dim3(64), 0, st, out16);     // 64 blocks: every XCD gets some
+  return dsr_launch_status("dsr_clock_sample");
+}

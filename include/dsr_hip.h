@@ -256,6 +256,10 @@ int dsr_ssim_blocks(int planes, int H, int W);
 int dsr_ssim_f32(const float* img1, const float* img2, int planes, int H, int W, float data_range, float* partial,
                  dsr_stream_t s);
 
+/* measurement aid: out16[2x] = shader-clock cycle counter (s_memtime) and out16[2x+1] = 100 MHz real-time counter
+ * (s_memrealtime) of XCD x (8 pairs; zero-fill before), read when the stream reaches this launch; two samples give the average
+ * shader clock of what ran between them (difference pairs of the same XCD only: the cycle counters are per XCD) */
+int dsr_clock_sample(unsigned long long* out16, dsr_stream_t s);
 /* ---- data-side byte kernels (dataset.py:9-62,121-159; utils/degradation.py:5-20) on device-resident
  * uint8 HWC images.  Integer / byte arithmetic, bit-identical to Pillow / numpy.
  * dsr_resample_u8: ONE pass of Pillow's 8-bit resampler along `axis` (1 = width, 0 = height); `bounds` [out_size][2] and `kk`
