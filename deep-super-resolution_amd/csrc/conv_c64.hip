@@ -41,23 +41,26 @@ __device__ __forceinline__ float vmax(float a, float b) {
 // order, so a load issued in the epilogue would wait for that DMA -- measured 82 us per trunk dgrad against 42 + 32 us for
 // dgrad and a separate add; mode 2 has no registers left for the prefetch).  Separate instantiations: the
 // layouts need different per-lane constants and the kernel has no registers to spare.
-template <int DT, int MODE>      // FOLD: inference epilogue (eval-mode BatchNorm scale/shift, residual); a separate
-                                 // instantiation because the training one has no registers to spare (249 of 256)
+// Tile = TR rows x 32 columns.  A wave owns a 16-COLUMN strip (wq) of all TR rows and a 32-channel half (wc): its m-tiles are
+// the tile's rows.  An A fragment (16 pixels of one halo row at one tap column) then serves up to three output rows
+// (tap rows 0, 1, 2), so a tile costs 6 (TR + 2) fragment reads for 36 TR MFMAs per wave -- 0.25 ds_read_b128 per MFMA at
+// TR = 4, against 0.5 when a wave owned one row of two 16-pixel halves and every fragment fed one row only.  (s_memtime
+// stamps of that form: the MFMA phase ran at 59 % of the single-wave MFMA rate with the LDS ~saturated by two blocks.)
+template <int DT, int MODE, int TR>
 __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   constexpr int HC = 40;                       // halo row pitch in pixels (34 used; multiple of 8 keeps the swizzle row-free)
-  constexpr int TR = 2;                        // tile rows (one per wave pair)
   constexpr int HRW = TR + 2;                  // halo rows
-  constexpr int X_BYTES = HRW * HC * 128;      // 20,480
+  constexpr int X_BYTES = HRW * HC * 128;      // 20,480 (TR = 2) | 30,720 (TR = 4)
   constexpr int C_STRIDE = 64 * 2 + 16;
   // one LDS object (a second one beside an LDS-DMA target makes hipcc drain the DMA before every LDS read):
-  // two halo stages | C tile | statistics
+  // two halo stages | C tile | statistics (dynamic: 80,896 bytes at TR = 4, two blocks per CU = 161,792 of 163,840)
   constexpr int C_BYTES = TR * 32 * C_STRIDE;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X_BYTES + C_BYTES + 2 * 2 * 64 * 4];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sC = smem + 2 * X_BYTES;
   float (*sStat)[2][64] = reinterpret_cast<float (*)[2][64]>(smem + 2 * X_BYTES + C_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it (and what derives from it) in SGPRs
   const int g = lane >> 4, r16 = lane & 15;
-  const int wp = wave >> 1, wc = wave & 1;     // tile row, channel half (32 co)
+  const int wq = wave >> 1, wc = wave & 1;     // 16-column strip of the tile, channel half (32 co)
   const int c0 = blockIdx.y * 64;              // this block's slice of the output channels (Cout = 64 * gridDim.y)
   const unsigned short* __restrict__ W = reinterpret_cast<const unsigned short*>(a.w);
   unsigned short* __restrict__ Y = reinterpret_cast<unsigned short*>(a.y);
@@ -84,12 +87,12 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
       for (int nt = 0; nt < 2; ++nt)
         fw[t][kk][nt] = *reinterpret_cast<const U4*>(W + ((size_t)(t * a.CoutP + c0 + wc * 32 + nt * 16 + wrow)) * 64 + kk * 32 + g * 8);
 
-  // A-fragment LDS offsets: pixel column (tx + r16) -> (tx + r16)*128 + swizzled chunk; + row*HC*128 + hx*2048
+  // A-fragment LDS offsets: halo column (16 wq + tx + r16) -> *128 + swizzled chunk (key = column & 7); + halo row * HC * 128
   int lds_off[3][2];
 #pragma unroll
   for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) lds_off[tx][kk] = (tx + r16) * 128 + (((4 * kk + g) ^ ((tx + r16) & 7)) << 4);
+    for (int kk = 0; kk < 2; ++kk) lds_off[tx][kk] = (16 * wq + tx + r16) * 128 + (((4 * kk + g) ^ ((tx + r16) & 7)) << 4);
 
   // loader: LDS-DMA (buffer_load ... lds): wave-instruction u of wave w fills halo slots 32u + 8w .. +7 (8 pixels x
   // 128 B, lane-linear), slot position (lane & 7) of pixel q holding channel chunk (lane & 7) ^ (q & 7); an
@@ -99,7 +102,8 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   // every address is a tile-invariant per-lane part (computed once per launch) plus a per-tile SCALAR part, the image
   // ROWS outside [0, H) are rejected by the buffer range check of a per-image resource, and the COLUMN check runs only
   // for tiles that touch the left / right image edge.
-  constexpr int NV = (HRW * HC + 31) / 32;     // 5
+  constexpr int NV = (HRW * HC + 31) / 32;     // 5 | 8 (the last one covers 16 slots only at TR = 4: waves 2, 3 sit it out)
+  constexpr int LAST_WAVES = ((HRW * HC) % 32 == 0) ? 4 : ((HRW * HC) % 32) / 8;
   constexpr unsigned OOB = 0xFFFFFFF0u;
   constexpr int FAR = 0x7FFFFF00;              // lane part of a slot that is never fetched: any scalar part leaves it out of range
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -108,14 +112,15 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   const int per_img = a.tiles_y * a.tiles_x;
   const unsigned img_bytes = (unsigned)(a.H * a.W * 128);
   int ld_part[NV];                             // ((hr * W + hc) * 64 + chunk * 8) * 2 of this lane's slot
-  unsigned hc_pack = 0;                        // its halo column, 6 bits per wave-instruction
+  typedef typename std::conditional<(6 * NV > 32), unsigned long long, unsigned>::type hc_pack_t;
+  hc_pack_t hc_pack = 0;                       // its halo column, 6 bits per wave-instruction
   {
     const int c = (tid & 7) ^ ((tid >> 3) & 7), pb = tid >> 3;
     int hr = pb / HC, hc = pb - hr * HC;
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       ld_part[u] = (hr < HRW && hc < 34) ? ((hr * a.W + hc) * 64 + c * 8) * 2 : FAR;   // pad columns 34..39 are never read
-      hc_pack |= (unsigned)hc << (6 * u);
+      hc_pack |= (hc_pack_t)hc << (6 * u);
       hc += 32;
       if (hc >= HC) {
         hc -= HC;
@@ -158,16 +163,20 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
         const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x)) + (size_t)n * img_bytes, 0, img_bytes, 0x00020000);
     const int sbase = (oy0 * a.W + ox0) * 128;                                    // may be negative (row -1): out of range
     unsigned char* dst = smem + buf * X_BYTES + 8 * wave * 128;
+    // (a DMA piece writes its 8 slots whatever the offsets are -- zeros for out-of-range ones --, so the waves whose slots of
+    //  the last piece lie behind the stage must not issue it: wave-uniform)
     if (ox0 >= 0 && ox0 + 34 <= a.W) {                                            // interior columns: no per-lane check
 #pragma unroll
       for (int u = 0; u < NV; ++u)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + 32 * u * 128), 16, (unsigned)(ld_part[u] + sbase), 0, 0, 0);
+        if (u + 1 < NV || wave < LAST_WAVES)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + 32 * u * 128), 16, (unsigned)(ld_part[u] + sbase), 0, 0, 0);
     } else {
 #pragma unroll
       for (int u = 0; u < NV; ++u) {
         const int ix = ox0 + (int)((hc_pack >> (6 * u)) & 63);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + 32 * u * 128), 16,
-                                                 (unsigned)ix < (unsigned)a.W ? (unsigned)(ld_part[u] + sbase) : OOB, 0, 0, 0);
+        if (u + 1 < NV || wave < LAST_WAVES)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + 32 * u * 128), 16,
+                                                   (unsigned)ix < (unsigned)a.W ? (unsigned)(ld_part[u] + sbase) : OOB, 0, 0, 0);
       }
     }
   };
@@ -187,19 +196,17 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
 
   // C tile in LDS: pixel rows of 64 channels.  PixelShuffle(2) launches store channel 4c + s at byte s*32 + c*2, i.e.
   // already grouped by sub-pixel, so that the store loop reads whole 16-byte vectors in both layouts.
-  int cw_base[2];                              // this lane's write address in the C tile for n-tile nt:
-#pragma unroll                                 //   pixel-major: pixel (wp*32 + 4g [+ 16 i + r]), one channel;
-  for (int nt = 0; nt < 2; ++nt) {             //   swapped: pixel (wp*32 + r16 [+ 16 i]), 4 channels (8 bytes)
+  int cw_base[2];                              // this lane's write address in the C tile for n-tile nt (tile pixel = 32 row + column):
+#pragma unroll                                 //   pixel-major: pixel (16 wq + 4g [+ 32 i + r]), one channel;
+  for (int nt = 0; nt < 2; ++nt) {             //   swapped: pixel (16 wq + r16 [+ 32 i]), 4 channels (8 bytes)
     const int col = wc * 32 + nt * 16 + r16;
     if constexpr (!swp)
-      cw_base[nt] = (wp * 32 + 4 * g) * C_STRIDE + (pixshuf ? (col & 3) * 32 + (col >> 2) * 2 : col * 2);
+      cw_base[nt] = (wq * 16 + 4 * g) * C_STRIDE + (pixshuf ? (col & 3) * 32 + (col >> 2) * 2 : col * 2);
     else
-      cw_base[nt] = (wp * 32 + r16) * C_STRIDE + (pixshuf ? g * 32 + (wc * 8 + nt * 4) * 2 : (wc * 32 + nt * 16 + 4 * g) * 2);
+      cw_base[nt] = (wq * 16 + r16) * C_STRIDE + (pixshuf ? g * 32 + (wc * 8 + nt * 4) * 2 : (wc * 32 + nt * 16 + 4 * g) * 2);
   }
-  // store loop: thread tid moves the 16-byte vectors idx = tid, tid + 256 of the tile (pixel idx >> 3, vector idx & 7)
+  // store loop: thread tid moves the 16-byte vectors idx = tid + 256 it of the tile (pixel idx >> 3, vector idx & 7): row `it`
   const int cr_base = (tid >> 3) * C_STRIDE + (tid & 7) * 16;          // + it * 32 * C_STRIDE
-  const int st_row = tid >> 8;                                         // 0 (kept for clarity: idx >> 8 selects `it`)
-  (void)st_row;
   int st_part;                                                          // byte offset of vector `tid` relative to the tile origin
   int st_step;                                                          // ... and of vector tid + 256 relative to vector tid
   if (!pixshuf) {
@@ -226,18 +233,18 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   for (; t < a.ntiles; t += tstep, buf ^= 1) {
     STAMP(0);
     // my DMA of this tile is done; after the barrier everyone's is, and every wave is past the previous tile.
-    // The previous tile's two output stores per thread (always issued: range-checked buffer stores) are younger than
+    // The previous tile's TR output stores per thread (always issued: range-checked buffer stores) are younger than
     // this tile's DMA and stay in flight through the MFMA phase: vmcnt retires in order, so "at most 2 outstanding"
-    // already means the DMA has landed.  A vmcnt(0) here exposed the full store latency once per 72-MFMA tile.
+    // "at most TR outstanding" already means the DMA has landed.  A vmcnt(0) here exposed the full store latency per tile.
     if (first)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TR) : "memory");
     first = false;
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     STAMP(1);
-    [[maybe_unused]] U4 rres[2];
+    [[maybe_unused]] U4 rres[TR];
     if constexpr (RES_EARLY) {
       // this tile's residual vectors (the two this thread will store over), requested BEFORE the next tile's DMA
       const int rn = cur.n, roy0 = cur.ty * TR, rox0 = cur.tx * 32;
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
       const unsigned rorg = (unsigned)(((rn * a.H + roy0) * a.W + rox0) * a.CoutP * 2 + c0 * 2);
       const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res), 0, a.y_bytes, 0x00020000);
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
+      for (int it = 0; it < TR; ++it) {
         unsigned off = rorg + (unsigned)(st_part + it * st_step);
         if (!rfull) {
           const int prow = (tid >> 3) + it * 32;
@@ -258,41 +265,43 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     const unsigned char* sX = smem + buf * X_BYTES;
     STAMP(2);
 
-    f32x4 acc[2][2];                           // m-tile = half hx of the wave's row ; n-tile nt
+    f32x4 acc[TR][2];                          // m-tile = tile row i (this wave's 16 columns of it) ; n-tile nt
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int k = 0; k < 2; ++k)                // bias: free here
         acc[i][k] = f32x4{bias_v[k][0], bias_v[k][1 % NB], bias_v[k][2 % NB], bias_v[k][3 % NB]};
-    // tap order is a compile-time property of each branch (forward: tap t = (t/3, t%3); dgrad: mirrored), so every
-    // A-fragment address is a per-lane base register + an immediate: no address arithmetic between the MFMAs.
-    // The 18 (tap, k-half) units run as a software pipeline: the two A fragments of unit u + 2 are requested before
-    // the 4 MFMAs of unit u (three register sets), so an LDS read has 8 MFMAs (128 cycles) to land instead of being
-    // waited for right after its issue -- hipcc otherwise reuses one register set and exposes the LDS latency 18 times.
+    // Fragment f = (tap column tx, k-half kk, halo row h), h innermost: 6 (TR + 2) of them per tile.  The fragment of halo row h
+    // feeds output rows i = h - ty for the tap rows ty = 0, 1, 2 that stay inside the tile (2 MFMAs per row: two n-tiles).
+    // Tap order is a compile-time property of each branch (forward: weight tap (ty, tx); dgrad: mirrored), so every fragment
+    // address is a per-lane base register + an immediate.  Software pipeline: the fragment f + 2 is requested before the
+    // MFMAs of fragment f (three rolling registers), pinned with sched_barriers -- hipcc otherwise reuses one register and
+    // exposes the LDS latency per fragment.
     auto mfma_phase = [&](auto mirror, auto swapped) {
       constexpr bool MIR = decltype(mirror)::value;
       constexpr bool SWP = decltype(swapped)::value;
-      const unsigned char* rowp0 = sX + wp * HC * 128;
-      U4 fa[3][2];
-      auto load = [&](int u, U4* dst) {
-        const int tp = u >> 1, kk = u & 1;
-        const int ty = MIR ? 2 - tp / 3 : tp / 3, tx = MIR ? 2 - tp % 3 : tp % 3;
-        const unsigned char* rowp = rowp0 + ty * HC * 128;
-        dst[0] = *reinterpret_cast<const U4*>(rowp + lds_off[tx][kk]);
-        dst[1] = *reinterpret_cast<const U4*>(rowp + 2048 + lds_off[tx][kk]);
+      constexpr int NF = 6 * HRW;
+      U4 fa[3];
+      auto load = [&](int f) {
+        const int u = f / HRW, h = f - u * HRW;  // u = tx * 2 + kk
+        return *reinterpret_cast<const U4*>(sX + h * HC * 128 + lds_off[u >> 1][u & 1]);
       };
-      load(0, fa[0]);
-      load(1, fa[1]);
+      fa[0] = load(0);
+      fa[1] = load(1);
 #pragma unroll
-      for (int u = 0; u < 18; ++u) {
-        if (u + 2 < 18) load(u + 2, fa[(u + 2) % 3]);
+      for (int f = 0; f < NF; ++f) {
+        if (f + 2 < NF) fa[(f + 2) % 3] = load(f + 2);
         __builtin_amdgcn_sched_barrier(0);       // (the machine scheduler would sink the reads back to their use)
-        const int tp = u >> 1, kk = u & 1;
+        const int u = f / HRW, h = f - u * HRW, tx = u >> 1, kk = u & 1;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int ty = 0; ty < 3; ++ty) {
+          const int i = h - ty;                  // output row fed through tap row ty
+          if (i < 0 || i >= TR) continue;
+          const int tp = MIR ? (2 - ty) * 3 + (2 - tx) : ty * 3 + tx;     // weight tap whose halo offset is (ty, tx)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
-            acc[i][nt] = SWP ? mfma16<DT>(fw[tp][kk][nt], fa[u % 3][i], acc[i][nt]) : mfma16<DT>(fa[u % 3][i], fw[tp][kk][nt], acc[i][nt]);
+            acc[i][nt] = SWP ? mfma16<DT>(fw[tp][kk][nt], fa[f % 3], acc[i][nt]) : mfma16<DT>(fa[f % 3], fw[tp][kk][nt], acc[i][nt]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
         }
     }
     // SM: 0 no statistics, 1 statistics of a full tile, 2 statistics of a ragged tile (out-of-image pixels masked)
-    static_assert(16 * C_STRIDE == 2304, "immediate of the second ds_write_b64 below");
+    static_assert(32 * C_STRIDE == 4608, "immediates of the ds_write_b64 below");
     const unsigned sC_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)sC);
     const unsigned cw_lds[2] = {sC_lds + (unsigned)cw_base[0], sC_lds + (unsigned)cw_base[1]};
     auto epilogue = [&](auto actf, auto smode) {
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
+          for (int i = 0; i < TR; ++i) {
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = actf(FOLD ? acc[i][nt][r] * sc_v[nt][r] + sh_v[nt][r] : acc[i][nt][r]);
@@ -355,10 +364,15 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
             }
             // inline asm: behind an in-flight LDS-DMA hipcc puts s_waitcnt vmcnt(0) in front of an 8-byte LDS store
             // it can see (the next tile's halo and the previous tile's output stores would be drained here)
-            if (i == 0)
+            if (i == 0)                       // (i is a constant after unrolling: one of these survives)
               asm volatile("ds_write_b64 %0, %1" ::"v"(cw_lds[nt]), "v"(pk) : "memory");
+            else if (i == 1)
+              asm volatile("ds_write_b64 %0, %1 offset:4608" ::"v"(cw_lds[nt]), "v"(pk) : "memory");    // i * 32 * C_STRIDE
+            else if (i == 2)
+              asm volatile("ds_write_b64 %0, %1 offset:9216" ::"v"(cw_lds[nt]), "v"(pk) : "memory");
             else
-              asm volatile("ds_write_b64 %0, %1 offset:2304" ::"v"(cw_lds[nt]), "v"(pk) : "memory");   // 16 * C_STRIDE
+              asm volatile("ds_write_b64 %0, %1 offset:13824" ::"v"(cw_lds[nt]), "v"(pk) : "memory");
+            static_assert(TR <= 4, "offsets above");
           }
         return;
       }
@@ -366,17 +380,17 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
       for (int nt = 0; nt < 2; ++nt) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TR; ++i) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float val = acc[i][nt][r];             // (FOLD launches are always swapped)
             if constexpr (SM != 0) {
               float vm = val;
-              if constexpr (SM == 2) vm = (oy0 + wp < a.H && ox0 + i * 16 + 4 * g + r < a.W) ? val : 0.f;
+              if constexpr (SM == 2) vm = (oy0 + i < a.H && ox0 + wq * 16 + 4 * g + r < a.W) ? val : 0.f;
               s1 += vm;
               s2 += vm * vm;
             }
-            *reinterpret_cast<unsigned short*>(sC + cw_base[nt] + (i * 16 + r) * C_STRIDE) = f2h<DT>(actf(val));
+            *reinterpret_cast<unsigned short*>(sC + cw_base[nt] + (i * 32 + r) * C_STRIDE) = f2h<DT>(actf(val));
           }
         }
         if constexpr (SM != 0) {
@@ -385,8 +399,8 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
           s2 += __shfl_xor(s2, 16, 64);
           s2 += __shfl_xor(s2, 32, 64);
           if (g == 0) {
-            sStat[wp][0][wc * 32 + nt * 16 + r16] = s1;
-            sStat[wp][1][wc * 32 + nt * 16 + r16] = s2;
+            sStat[wq][0][wc * 32 + nt * 16 + r16] = s1;
+            sStat[wq][1][wc * 32 + nt * 16 + r16] = s2;
           }
         }
       }
@@ -424,11 +438,11 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
       stat_acc += sStat[0][which][col] + sStat[1][which][col];
     }
     {
-      // exactly 2 stores per thread (see the wait above).  Scalar part: byte offset of the tile origin in y.
+      // exactly TR stores per thread (see the wait above).  Scalar part: byte offset of the tile origin in y.
       const unsigned sorg = pixshuf ? (unsigned)(((n * 2 * a.H + 2 * oy0) * (2 * a.W) + 2 * ox0) * (a.CoutP / 4) * 2 + (c0 / 4) * 2)
                                     : (unsigned)(((n * a.H + oy0) * a.W + ox0) * a.CoutP * 2 + c0 * 2);
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
+      for (int it = 0; it < TR; ++it) {
         U4 v = *reinterpret_cast<const U4*>(sC + cr_base + it * 32 * C_STRIDE);
         unsigned off = sorg + (unsigned)(st_part + it * st_step);
         if (!full) {                                                    // (uniform) ragged tile: per-lane range check
@@ -465,44 +479,65 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
 #endif
 }
 
-// statistics rows written by one launch (= spatial tiles)
-int dsr_c64_tiles(int N, int H, int W) {
-  return N * ((H + 1) / 2) * ((W + 31) / 32);
+// tile rows per mode -- as many as the 256-register budget of two resident blocks allows WITHOUT a single spill (a spill is a
+// VMEM instruction: it would break the "exactly TR stores outstanding" count the tile loop waits on): plain 4, statistics 3
+// (the pixel-major epilogue needs more temporaries) and residual prefetch 3, folded inference epilogue 2
+static constexpr int c64_tile_rows(int mode) { return mode == 1 ? 4 : (mode == 2 ? 2 : 3); }
+static constexpr int c64_lds_bytes(int tr) { return 2 * (tr + 2) * 40 * 128 + tr * 32 * (64 * 2 + 16) + 2 * 2 * 64 * 4; }
+
+// spatial tiles of a launch whose tiles are `tr` rows x 32 columns
+int dsr_c64_tiles(int N, int H, int W, int tr) {
+  return N * ((H + tr - 1) / tr) * ((W + 31) / 32);
 }
-// BatchNorm statistics rows written by one launch: one per persistent block of a 64-channel output slice
+// BatchNorm statistics rows written by one launch (always mode 0): one per persistent block of a 64-channel output slice
 int dsr_c64_stat_rows(int N, int H, int W, int CoutP) {
-  const int ntiles = dsr_c64_tiles(N, H, W), per_slice = 512 / (CoutP / 64);
+  const int ntiles = dsr_c64_tiles(N, H, W, c64_tile_rows(0)), per_slice = 512 / (CoutP / 64);
   return ntiles < per_slice ? ntiles : per_slice;
 }
 
+template <int DT, int MODE>
+static void c64_launch(const C64Args& a, dim3 grid, hipStream_t st) {
+  constexpr int TR = c64_tile_rows(MODE);
+  constexpr int LDS = c64_lds_bytes(TR);
+  auto* fn = conv_c64_kernel<DT, MODE, TR>;
+  if constexpr (LDS > 64 * 1024) {
+    static bool done = false;       // more than 64 KB of dynamic LDS needs the opt-in, once per kernel (not a stream operation)
+    if (!done) {
+      (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(256), LDS, st, a);
+}
+
 void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st) {
-  a.tiles_y = (a.H + 1) / 2;
-  a.tiles_x = (a.W + 31) / 32;
-  a.ntiles = N * a.tiles_y * a.tiles_x;
-  a.x_bytes = (unsigned)((size_t)N * a.H * a.W * 128);
-  a.y_bytes = (unsigned)((size_t)N * a.H * a.W * a.CoutP * 2);   // (PixelShuffle: [N][2H][2W][CoutP/4] is the same size)
   const int slices = a.CoutP / 64;                            // blockIdx.y: 64-channel slice of the output
-  int per_slice = 512 / slices;                               // 2 resident blocks per CU over all slices
-#ifdef DSR_C64_STAMPS
-  if (const char* e = getenv("DSR_C64_BLOCKS")) per_slice = atoi(e) / slices;
-#endif
-  dim3 grid(a.ntiles < per_slice ? a.ntiles : per_slice, slices), block(256);
   const bool fold = (a.flags & (DSR_F_AFFINE | DSR_F_RESIDUAL)) != 0;
   // residual alone, no activation, no PixelShuffle, one 64-channel slice (the input gradient of a residual block): mode 3
   const bool res_only = (a.flags & DSR_F_RESIDUAL) && !(a.flags & (DSR_F_AFFINE | DSR_F_PIXSHUF | DSR_F_STATS)) &&
                         a.act == DSR_ACT_NONE && slices == 1;
   const int mode = res_only ? 3 : (fold ? 2 : ((a.flags & DSR_F_STATS) ? 0 : 1));
-#define C64_LAUNCH(DTV, M) hipLaunchKernelGGL((conv_c64_kernel<DTV, M>), grid, block, 0, st, a)
-  if (dtype == DSR_DTYPE_BF16) {
-    if (mode == 3) C64_LAUNCH(DSR_DTYPE_BF16, 3);
-    else if (mode == 2) C64_LAUNCH(DSR_DTYPE_BF16, 2);
-    else if (mode == 1) C64_LAUNCH(DSR_DTYPE_BF16, 1);
-    else C64_LAUNCH(DSR_DTYPE_BF16, 0);
-  } else {
-    if (mode == 3) C64_LAUNCH(DSR_DTYPE_F16, 3);
-    else if (mode == 2) C64_LAUNCH(DSR_DTYPE_F16, 2);
-    else if (mode == 1) C64_LAUNCH(DSR_DTYPE_F16, 1);
-    else C64_LAUNCH(DSR_DTYPE_F16, 0);
-  }
+  const int tr = c64_tile_rows(mode);
+  a.tiles_y = (a.H + tr - 1) / tr;
+  a.tiles_x = (a.W + 31) / 32;
+  a.ntiles = N * a.tiles_y * a.tiles_x;
+  a.x_bytes = (unsigned)((size_t)N * a.H * a.W * 128);
+  a.y_bytes = (unsigned)((size_t)N * a.H * a.W * a.CoutP * 2);   // (PixelShuffle: [N][2H][2W][CoutP/4] is the same size)
+  int per_slice = 512 / slices;                               // 2 resident blocks per CU over all slices
+#ifdef DSR_C64_STAMPS
+  if (const char* e = getenv("DSR_C64_BLOCKS")) per_slice = atoi(e) / slices;
+#endif
+  dim3 grid(a.ntiles < per_slice ? a.ntiles : per_slice, slices);
+#define C64_LAUNCH(DTV)                              \
+  do {                                               \
+    if (mode == 3) c64_launch<DTV, 3>(a, grid, st);   \
+    else if (mode == 2) c64_launch<DTV, 2>(a, grid, st); \
+    else if (mode == 1) c64_launch<DTV, 1>(a, grid, st); \
+    else c64_launch<DTV, 0>(a, grid, st);            \
+  } while (0)
+  if (dtype == DSR_DTYPE_BF16)
+    C64_LAUNCH(DSR_DTYPE_BF16);
+  else
+    C64_LAUNCH(DSR_DTYPE_F16);
 #undef C64_LAUNCH
 }

@@ -166,7 +166,7 @@ struct C64Args {
   int tap_y[9], tap_x[9];   // halo-relative row / column offset (0..2) of weight slice t
   unsigned x_bytes, y_bytes;
 };
-int dsr_c64_tiles(int N, int H, int W);
+int dsr_c64_tiles(int N, int H, int W, int tile_rows);
 int dsr_c64_stat_rows(int N, int H, int W, int CoutP);
 void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st);
 
