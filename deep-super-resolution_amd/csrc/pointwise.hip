@@ -468,6 +468,10 @@ __device__ __forceinline__ U4 ld16(const unsigned short* p) {
   return NT ? __builtin_nontemporal_load(reinterpret_cast<const U4*>(p)) : *reinterpret_cast<const U4*>(p);
 }
 template <bool NT>
+__device__ __forceinline__ unsigned ld4(const unsigned short* p) {
+  return NT ? __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p)) : *reinterpret_cast<const unsigned*>(p);
+}
+template <bool NT>
 __device__ __forceinline__ void st16(unsigned short* p, const U4& v) {
   if (NT) __builtin_nontemporal_store(v, reinterpret_cast<U4*>(p)); else *reinterpret_cast<U4*>(p) = v;
 }
@@ -774,28 +778,46 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const unsigned short* __re
       one(d, o, p);
     }
   } else if (rr < rpi) {
-    for (size_t p = p0 + rr; p < p1; p += rpi) {
-      float d[8], o[8];
-      {
-        int w = (int)(p % W);
-        int h = (int)((p / W) % H);
-        int n = (int)(p / ((size_t)W * H));
-        // conv channels 8ch..8ch+7 = shuffle channels c0, c0+1 (c0 = 2ch) at the 4 sub-pixels: one 4-byte load per
-        // sub-pixel and tensor instead of eight 2-byte gathers
-        const int c0 = ch * 2;
-        const bool cok = c0 < CoP;
+    // PixelShuffle(2) un-shuffle: conv channels 8ch..8ch+7 = shuffle channels c0, c0+1 (c0 = 2ch) at the 4 sub-pixels: one
+    // 4-byte load per sub-pixel and tensor instead of eight 2-byte gathers (a conv pixel's 32 lanes read 128 contiguous bytes
+    // per sub-pixel).  Two conv pixels in flight per thread (16 loads), 32-bit index arithmetic (P < 2^31 here).
+    const int c0 = ch * 2;
+    const bool cok = c0 < CoP;
+    auto gather = [&](int p, unsigned (&dv)[4], unsigned (&ov)[4]) {
+      const int n = p / (W * H);
+      const int rem = p - n * (W * H);
+      const int h = rem / W, w = rem - h * W;
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-          const size_t q = ((size_t)(n * 2 * H + 2 * h + (sub >> 1)) * (2 * W) + 2 * w + (sub & 1)) * CoP + c0;
-          const unsigned dv = cok ? *reinterpret_cast<const unsigned*>(dout + q) : 0u;
-          const unsigned ov = cok ? *reinterpret_cast<const unsigned*>(out + q) : 0u;
-          d[sub] = h2f<DT>((unsigned short)(dv & 0xffff));
-          d[4 + sub] = h2f<DT>((unsigned short)(dv >> 16));
-          o[sub] = h2f<DT>((unsigned short)(ov & 0xffff));
-          o[4 + sub] = h2f<DT>((unsigned short)(ov >> 16));
-        }
+      for (int sub = 0; sub < 4; ++sub) {
+        const size_t q = ((size_t)(n * 2 * H + 2 * h + (sub >> 1)) * (2 * W) + 2 * w + (sub & 1)) * CoP + c0;
+        dv[sub] = cok ? ld4<NT>(dout + q) : 0u;
+        ov[sub] = cok ? ld4<NT>(out + q) : 0u;
+      }
+    };
+    auto finish = [&](const unsigned (&dv)[4], const unsigned (&ov)[4], size_t p) {
+      float d[8], o[8];
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        d[sub] = h2f<DT>((unsigned short)(dv[sub] & 0xffff));
+        d[4 + sub] = h2f<DT>((unsigned short)(dv[sub] >> 16));
+        o[sub] = h2f<DT>((unsigned short)(ov[sub] & 0xffff));
+        o[4 + sub] = h2f<DT>((unsigned short)(ov[sub] >> 16));
       }
       one(d, o, p);
+    };
+    int p = (int)p0 + rr;
+    const int pe = (int)p1;
+    for (; p + rpi < pe; p += 2 * rpi) {
+      unsigned dv0[4], ov0[4], dv1[4], ov1[4];
+      gather(p, dv0, ov0);
+      gather(p + rpi, dv1, ov1);
+      finish(dv0, ov0, (size_t)p);
+      finish(dv1, ov1, (size_t)(p + rpi));
+    }
+    if (p < pe) {
+      unsigned dv0[4], ov0[4];
+      gather(p, dv0, ov0);
+      finish(dv0, ov0, (size_t)p);
     }
   }
   if (partial == nullptr) return;
