@@ -34,6 +34,8 @@ _DESC = C.POINTER(ConvDesc)
 SIGNATURES = {
     "dsr_last_error": (C.c_char_p, []),
     "dsr_abi_version": (_I, []),
+    "dsr_conv_dgrad_masked_supported": (_I, [_DESC]),
+    "dsr_conv_dgrad_masked": (_I, [_DESC, _P, _P, _P, _I, _F, _P, _P]),
     "dsr_conv_dgrad_add_supported": (_I, [_DESC]),
     "dsr_conv_dgrad_add": (_I, [_DESC, _P, _P, _P, _P, _P]),
     "dsr_conv_wgrad_batchable": (_I, [_DESC]),
@@ -96,6 +98,7 @@ SIGNATURES = {
     "dsr_dense2_bwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "dsr_maxpool2_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "dsr_maxpool2_bwd": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dsr_maxpool2_relu_bwd": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dsr_avgpool2_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "dsr_avgpool2_bwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "dsr_nearest2x_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
@@ -116,7 +119,7 @@ _lib = None
 # bench.py's roofline leg: a list here makes every launching entry point record (name, start_event, end_event) on the
 # stream it launches on (torch's current stream), so that the GPU-busy share of a step can be told from launch gaps.
 LAUNCH_LOG = None
-_NO_LAUNCH = ("dsr_last_error", "dsr_abi_version", "dsr_conv_kernel_name", "dsr_conv_wgrad_batchable", "dsr_conv_wgrad_batched_workspace", "dsr_conv_dgrad_add_supported", "dsr_conv_fwd_affine_supported",
+_NO_LAUNCH = ("dsr_last_error", "dsr_abi_version", "dsr_conv_kernel_name", "dsr_conv_wgrad_batchable", "dsr_conv_wgrad_batched_workspace", "dsr_conv_dgrad_add_supported", "dsr_conv_dgrad_masked_supported", "dsr_conv_fwd_affine_supported",
               "dsr_conv_first_bwd_supported", "dsr_conv_first_bwd_workspace", "dsr_conv_out_size", "dsr_conv_stats_rows",
               "dsr_conv_packed_elems", "dsr_conv_dgrad_workspace", "dsr_conv_wgrad_workspace", "dsr_pw_scratch_rows",
               "dsr_pw_reduce_blocks", "dsr_linear_fwd_workspace", "dsr_ssim_blocks")

@@ -286,7 +286,7 @@ __global__ void reflect_fold_kernel(const unsigned short* __restrict__ dxp, unsi
 }
 
 static void launch_c64_dgrad(const dsr_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, void* dx,
-                             dsr_stream_t s) {
+                             dsr_stream_t s, int mask_act = DSR_ACT_NONE, float mask_slope = 0.f) {
   C64Args c;
   memset(&c, 0, sizeof(c));
   c.CoutP = 64;
@@ -295,6 +295,11 @@ static void launch_c64_dgrad(const dsr_conv_desc* d, const void* dy, const void*
   c.y = dx;
   c.res = addend;                       // dx = dgrad(dy) + addend: the skip path's gradient rides in the epilogue
   c.flags = addend ? DSR_F_RESIDUAL : 0;
+  if (addend && mask_act != DSR_ACT_NONE) {   // ... or dx = dgrad(dy) * act'(addend): the tile is an activation output
+    c.flags |= DSR_F_MASK;
+    c.mask_act = mask_act;
+    c.mask_slope = mask_slope;
+  }
   c.H = d->H;
   c.W = d->W;
   c.act = DSR_ACT_NONE;
@@ -312,8 +317,11 @@ extern "C" size_t dsr_conv_dgrad_workspace(const dsr_conv_desc* d) {
   return (size_t)d->N * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * r8(d->Cin) * 2;
 }
 
-extern "C" int dsr_conv_dgrad(const dsr_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* workspace,
-                              size_t ws_bytes, dsr_stream_t s) {
+static bool dgrad_mask_supported(const dsr_conv_desc* d);
+
+// mask_x != null: dx = dgrad(dy) * act'(mask_x) (dsr_conv_dgrad_masked; the caller has checked dgrad_mask_supported)
+static int conv_dgrad_impl(const dsr_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* workspace,
+                           size_t ws_bytes, const void* mask_x, int mask_act, float mask_slope, dsr_stream_t s) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!dy || !w_dgrad || !dx) return dsr_fail(DSR_E_ARG, "conv_dgrad: null pointer");
@@ -333,7 +341,7 @@ extern "C" int dsr_conv_dgrad(const dsr_conv_desc* d, const void* dy, const void
     target = workspace;
   }
   if (is_c64(d)) {   // mirrored taps on the [tap][ci][co] weight image
-    launch_c64_dgrad(d, dy, w_dgrad, nullptr, dx, s);
+    launch_c64_dgrad(d, dy, w_dgrad, mask_x, dx, s, mask_act, mask_slope);
     return dsr_launch_status("dsr_conv_dgrad(c64)");
   }
   if (is_tail9(d)) {   // the generator's 9x9 64->3 tail: Toeplitz K = (kw, co) mapping (conv_smalln.hip)
@@ -404,6 +412,9 @@ extern "C" int dsr_conv_dgrad(const dsr_conv_desc* d, const void* dy, const void
       a.oox = pw;
       a.pad_mode = DSR_PAD_ZERO;
       a.act = DSR_ACT_NONE;
+      a.mask_x = mask_x;
+      a.mask_act = mask_act;
+      a.mask_slope = mask_slope;
       int nt = 0;
       for (int kh = 0; kh < d->KH; ++kh) {
         if ((ph + pad - kh) % st != 0) continue;
@@ -428,6 +439,33 @@ extern "C" int dsr_conv_dgrad(const dsr_conv_desc* d, const void* dy, const void
                          (unsigned short*)dx, d->N, d->H, d->W, r8(d->Cin), d->pad);
   }
   return dsr_launch_status("dsr_conv_dgrad");
+}
+
+extern "C" int dsr_conv_dgrad(const dsr_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* workspace,
+                              size_t ws_bytes, dsr_stream_t s) {
+  return conv_dgrad_impl(d, dy, w_dgrad, dx, workspace, ws_bytes, nullptr, DSR_ACT_NONE, 0.f, s);
+}
+
+// dx = dgrad(dy) * act'(x_act): the backward of the activation that produced this conv's input, folded into the store loop
+// of the input-gradient kernel (x_act = the conv's own input = that activation's output; ReLU, or LeakyReLU with slope > 0).
+// Replaces the separate dsr_pw_act_bwd pass of the producing layer (read g, read o, write g') by one extra tile read --
+// the VGG19 trunk of the perceptual loss (utils/GAN.py:19-57) is a chain of such pairs.  Stride-1 zero-pad layers on the
+// 64 -> 64 kernel or the one-tile-per-block gather kernel; bit-identical to dsr_conv_dgrad followed by dsr_pw_act_bwd.
+static bool dgrad_mask_supported(const dsr_conv_desc* d) {
+  if (d->stride != 1 || d->pad_mode != DSR_PAD_ZERO || is_tail9(d) || is_smalln_dgrad(d)) return false;
+  if (is_c64(d)) return true;
+  return r8(d->Cout) % 64 == 0 && r8(d->Cin) >= 32;      // the gather kernel's LDS-DMA fast path with 16-byte output vectors
+}
+extern "C" int dsr_conv_dgrad_masked_supported(const dsr_conv_desc* d) { return d && !check_desc(d) && dgrad_mask_supported(d) ? 1 : 0; }
+extern "C" int dsr_conv_dgrad_masked(const dsr_conv_desc* d, const void* dy, const void* w_dgrad, const void* x_act, int act,
+                                     float slope, void* dx, dsr_stream_t s) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!dy || !w_dgrad || !x_act || !dx) return dsr_fail(DSR_E_ARG, "conv_dgrad_masked: null pointer");
+  if (act != DSR_ACT_RELU && !(act == DSR_ACT_LEAKY && slope > 0.f))
+    return dsr_fail(DSR_E_ARG, "conv_dgrad_masked: ReLU, or LeakyReLU with a positive slope (the branch is read off the output)");
+  if (!dgrad_mask_supported(d)) return dsr_fail(DSR_E_UNSUPPORTED, "conv_dgrad_masked: layer shape not taken (stride 1, zero padding, >= 32 input channels)");
+  return conv_dgrad_impl(d, dy, w_dgrad, dx, nullptr, 0, x_act, act, slope, s);
 }
 
 static void wgrad_plan(const dsr_conv_desc* d, WgradArgs& a) {

@@ -450,12 +450,16 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
           if (!(oy0 + (prow >> 5) < a.H && ox0 + (prow & 31) < a.W)) off = OOB;
         }
         if constexpr (RES_EARLY) {
-          float f[8], rr[8];
-          unpack8<DT>(v, f);
-          unpack8<DT>(rres[it], rr);
+          if (a.flags & DSR_F_MASK) {           // (uniform) the prefetched tile is an activation output: y = conv * act'(o)
+            v = act_mask8<DT>(v, rres[it], a.mask_act, a.mask_slope);
+          } else {
+            float f[8], rr[8];
+            unpack8<DT>(v, f);
+            unpack8<DT>(rres[it], rr);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) f[q] += rr[q];
-          v = pack8<DT>(f);
+            for (int q = 0; q < 8; ++q) f[q] += rr[q];
+            v = pack8<DT>(f);
+          }
         }
         if (FOLD && (a.flags & DSR_F_RESIDUAL)) {   // skip connection (generator.py:24,74): added after the activation
           float f[8], rr[8];
@@ -514,6 +518,7 @@ void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st) {
   const int slices = a.CoutP / 64;                            // blockIdx.y: 64-channel slice of the output
   const bool fold = (a.flags & (DSR_F_AFFINE | DSR_F_RESIDUAL)) != 0;
   // residual alone, no activation, no PixelShuffle, one 64-channel slice (the input gradient of a residual block): mode 3
+  // (DSR_F_MASK rides on the same prefetch: the tile is then an activation output whose derivative multiplies the result)
   const bool res_only = (a.flags & DSR_F_RESIDUAL) && !(a.flags & (DSR_F_AFFINE | DSR_F_PIXSHUF | DSR_F_STATS)) &&
                         a.act == DSR_ACT_NONE && slices == 1;
   const int mode = res_only ? 3 : (fold ? 2 : ((a.flags & DSR_F_STATS) ? 0 : 1));

@@ -640,6 +640,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 256 * 25
       const unsigned lpart = (unsigned)((tid / CH) * a.CoutP * 2 + (tid % CH) * 16);
       const unsigned step = (unsigned)((NT / CH) * a.CoutP * 2);
       const unsigned char* src = sC + (tid / CH) * C_STRIDE + (tid % CH) * 16;
+      if (a.mask_x) {       // (uniform) dgrad with the upstream activation's backward mask folded into the stores
+        const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.mask_x), 0, (unsigned)((size_t)a.M * a.CoutP * 2), 0x00020000);
+#pragma unroll
+        for (int it = 0; it < (BM * CH) / NT; ++it) {
+          const U4 v = *reinterpret_cast<const U4*>(src + it * (NT / CH) * C_STRIDE);
+          const U4 o = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(mr, sorg + lpart + it * step, 0, 0));
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned,
+                                                                    act_mask8<DT>(v, o, a.mask_act, a.mask_slope)),
+                                                 yr, sorg + lpart + it * step, 0, 0);
+        }
+        return;
+      }
 #pragma unroll
       for (int it = 0; it < (BM * CH) / NT; ++it) {
         const U4 v = *reinterpret_cast<const U4*>(src + it * (NT / CH) * C_STRIDE);
@@ -658,7 +670,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 256 * 25
         int gx = rem - gy * a.GW;
         int oy = gy * a.osy + a.ooy, ox = gx * a.osx + a.oox;
         size_t off = ((size_t)(n * a.OH + oy) * a.OW + ox) * a.CoutP + col0;
-        *reinterpret_cast<U4*>(Y + off) = *reinterpret_cast<const U4*>(sC + row * C_STRIDE + ch * 16);
+        U4 v = *reinterpret_cast<const U4*>(sC + row * C_STRIDE + ch * 16);
+        if (a.mask_x)
+          v = act_mask8<DT>(v, *reinterpret_cast<const U4*>(reinterpret_cast<const unsigned short*>(a.mask_x) + off), a.mask_act, a.mask_slope);
+        *reinterpret_cast<U4*>(Y + off) = v;
       }
     }
   } else {
@@ -780,8 +795,10 @@ static void dispatch_dt(const ConvGemmArgs& a, hipStream_t st) {
 }
 
 void dsr_launch_conv_gemm(const ConvGemmArgs& a, int dtype, hipStream_t st) {
-  if (dsr_launch_conv_gemm_persist(a, dtype, st)) return;   // many-tile fast-path launches: persistent kernel
-  if (dsr_launch_conv_gemm_big(a, dtype, st)) return;       // 256x256 tiles, more tiles than CUs: persistent form
+  if (!a.mask_x) {          // (the persistent kernels keep a DMA in flight across their epilogue: no masked form)
+    if (dsr_launch_conv_gemm_persist(a, dtype, st)) return;   // many-tile fast-path launches: persistent kernel
+    if (dsr_launch_conv_gemm_big(a, dtype, st)) return;       // 256x256 tiles, more tiles than CUs: persistent form
+  }
   if (dtype == DSR_DTYPE_BF16)
     dispatch_dt<DSR_DTYPE_BF16>(a, st);
   else

@@ -98,6 +98,19 @@ __device__ __forceinline__ float act_grad_from_out(int act, float o, float slope
   return o >= 0.f ? 1.f : slope;
 }
 
+// g * act'(o) on 8 packed 16-bit values, o = the activation OUTPUT (ReLU, or Leaky/PReLU with slope > 0): what act_bwd_kernel
+// computes per element (fp32 product, one rounding), so a kernel that applies it to its own rounded output is bit-identical
+// to that kernel followed by the separate pass.
+template <int DT>
+__device__ __forceinline__ U4 act_mask8(const U4& gv, const U4& ov, int act, float slope) {
+  float g[8], o[8];
+  unpack8<DT>(gv, g);
+  unpack8<DT>(ov, o);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) g[k] = g[k] * act_grad_from_out(act, o[k], slope);
+  return pack8<DT>(g);
+}
+
 __device__ __forceinline__ int pad_index(int i, int n, int mode, bool& inb) {
   // maps a possibly out-of-range coordinate (branch-free); inb=false means "contributes zero"
   const bool in = (unsigned)i < (unsigned)n;

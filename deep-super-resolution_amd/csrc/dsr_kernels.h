@@ -14,6 +14,7 @@
 #define DSR_F_PRELU_PTR 16
 #define DSR_F_AFFINE 32      // (acc + bias) * scale[c] + shift[c] before the activation (eval-mode BatchNorm folded in)
 #define DSR_F_RESIDUAL 64    // + residual tile after the activation
+#define DSR_F_MASK 128       // (conv_c64, with DSR_F_RESIDUAL): the `res` tile is an activation output o: y = conv * act'(o) instead of conv + res
 
 // q = floor(m / d) for 0 <= m < 2^31 via multiply-high (no integer division in kernels)
 struct FastDiv {
@@ -57,6 +58,11 @@ struct ConvGemmArgs {
   int flags;
   int tiles_m, tiles_n;
   FastDiv fd_ghw, fd_gw, fd_cu, fd_cu8;
+  // dsr_conv_dgrad_masked: the stored output is multiplied by act'(mask_x) (mask_x: the activation OUTPUT this gradient is
+  // taken with respect to, same shape as y); dense-output launches of the one-tile-per-block kernel only
+  const void* mask_x;
+  int mask_act;
+  float mask_slope;
   int taps[DSR_MAX_TAPS];   // (dy & 0xff) | (dx & 0xff) << 8 | widx << 16
 };
 
@@ -162,6 +168,8 @@ struct C64Args {
   int act;
   float slope;
   int flags;
+  int mask_act;        // DSR_F_MASK: activation whose derivative (from its output `res`) multiplies the result
+  float mask_slope;
   int tiles_y, tiles_x, ntiles;
   int tap_y[9], tap_x[9];   // halo-relative row / column offset (0..2) of weight slice t
   unsigned x_bytes, y_bytes;

@@ -37,7 +37,7 @@ __global__ void maxpool2_fwd_kernel(const unsigned short* __restrict__ x, unsign
 // dx at (y,x) = dy of its window iff (y,x) is the FIRST maximum of the window in scan order (ATen's choice)
 template <int DT>
 __global__ void maxpool2_bwd_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
-                                    unsigned short* __restrict__ dx, int N, int H, int W, int Cp) {
+                                    unsigned short* __restrict__ dx, int N, int H, int W, int Cp, int relu_mask) {
   const int OH = H / 2, OW = W / 2, cpr = Cp / 8;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)N * H * W * cpr;
@@ -69,7 +69,8 @@ __global__ void maxpool2_bwd_kernel(const unsigned short* __restrict__ x, const 
           m = v[q][k];
           arg = q;
         }
-      g[k] = arg == me ? d[k] : 0.f;
+      // relu_mask: x is a ReLU output and its backward rides along: the routed gradient survives where the maximum is > 0
+      g[k] = (arg == me && (!relu_mask || m > 0.f)) ? d[k] : 0.f;
     }
   }
   *reinterpret_cast<U4*>(dx + pix * Cp + ch * 8) = pack8<DT>(g);
@@ -400,8 +401,17 @@ extern "C" int dsr_maxpool2_bwd(int dtype, const void* x, const void* dy, void* 
   size_t total = (size_t)N * H * W * (Cp / 8);
   DT_SWITCH2(dtype, hipLaunchKernelGGL((maxpool2_bwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
                                        (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, N, H, W,
-                                       Cp));
+                                       Cp, 0));
   return dsr_launch_status("dsr_maxpool2_bwd");
+}
+extern "C" int dsr_maxpool2_relu_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int Cp,
+                                     dsr_stream_t st) {
+  DSR_REQUIRE(x && dy && dx && DSR_DTYPE_OK(dtype) && N > 0 && H >= 2 && W >= 2 && Cp >= 8 && Cp % 8 == 0, "maxpool2_relu_bwd: null pointer or bad shape");
+  size_t total = (size_t)N * H * W * (Cp / 8);
+  DT_SWITCH2(dtype, hipLaunchKernelGGL((maxpool2_bwd_kernel<DT>), dim3(nb(total)), dim3(256), 0, st,
+                                       (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)dx, N, H, W,
+                                       Cp, 1));
+  return dsr_launch_status("dsr_maxpool2_relu_bwd");
 }
 extern "C" int dsr_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t st) {
   DSR_REQUIRE(x && y && DSR_DTYPE_OK(dtype) && N > 0 && H > 0 && W > 0 && Cp >= 8 && Cp % 8 == 0, "avgpool2_fwd: null pointer or bad shape");

@@ -256,13 +256,33 @@ class batched_wgrad:
                 g.copy_(alias)                            # autograd stored a copy made before the launch: refresh it
 
 
-def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape, weight=None, addend=None):
-    """dx (+ `addend`: the gradient that reaches x along a skip path, summed in the dgrad epilogue where the kernel can) and dw."""
+ACT_LINKS = True      # development switch: False makes every layer run its own activation-backward pass (A/B of ActLink)
+
+
+class ActLink:
+    """Hand-over of an activation's backward between two neighbouring autograd nodes: the node that CONSUMES an activation
+    output x (a conv's input-gradient launch, a max-pool backward) can multiply its result by act'(x) on the way out
+    (dsr_conv_dgrad_masked, dsr_maxpool2_relu_bwd); it then sets `premasked`, and the node that PRODUCED x skips its own
+    activation-backward pass.  One link per activation and forward call; only for an x with exactly one consumer (the VGG19
+    trunk, utils/GAN.py:19-57)."""
+    __slots__ = ("act", "slope", "premasked")
+
+    def __init__(self, act, slope=0.0):
+        self.act, self.slope, self.premasked = act, float(slope), False
+
+
+def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape, weight=None, addend=None, in_link=None):
+    """dx (+ `addend`: the gradient that reaches x along a skip path, summed in the dgrad epilogue where the kernel can; or
+    `in_link`: the activation that produced x, whose backward mask is folded into the dgrad stores where the kernel can) and dw."""
     lib = _lib.lib()
     dx = dw = None
     if need_dx:
         dx = torch.empty_like(x)
-        if addend is not None and lib.dsr_conv_dgrad_add_supported(C.byref(desc)):
+        if in_link is not None and addend is None and lib.dsr_conv_dgrad_masked_supported(C.byref(desc)):
+            check(_timed("dgrad", desc, lambda: lib.dsr_conv_dgrad_masked(C.byref(desc), _ptr(dy), _ptr(wd), _ptr(x), in_link.act,
+                                                                            in_link.slope, _ptr(dx), _stream())))
+            in_link.premasked = True
+        elif addend is not None and lib.dsr_conv_dgrad_add_supported(C.byref(desc)):
             addend = addend.contiguous()
             check(_timed("dgrad", desc, lambda: lib.dsr_conv_dgrad_add(C.byref(desc), _ptr(dy), _ptr(wd), _ptr(addend), _ptr(dx),
                                                                          _stream()), name="conv_c64_kernel<3>"))
@@ -409,7 +429,14 @@ class ConvAct(torch.autograd.Function):
                 C.byref(desc), _ptr(x), _ptr(dout), _ptr(y), ctx.act, float(ctx.cfg.get("slope", 0.0)), _ptr(dw), _ptr(db),
                 _ptr(ws), wsz, _stream()), name="conv_first_bwd_kernel"))
             return None, dw, db, None, None
-        if ctx.act == ACT_NONE and not ctx.ps:
+        out_link = ctx.cfg.get("out_link")
+        if (out_link is not None and out_link.premasked and prelu is None and not ctx.ps
+                and not (ctx.has_bias and ctx.needs_input_grad[2])):
+            # the consumer of this layer's output already multiplied dout by act'(y) (ActLink): nothing left to do here
+            out_link.premasked = False
+            dy = dout
+            db = dprelu = None
+        elif ctx.act == ACT_NONE and not ctx.ps:
             dy = dout
             db = _colsum(dy, cout) if ctx.has_bias else None
             dprelu = None
@@ -431,7 +458,7 @@ class ConvAct(torch.autograd.Function):
                 dprelu = torch.empty(1, dtype=torch.float32, device=x.device)
                 check(lib.dsr_pw_sum_rows(_ptr(chan), cyp, 1, 0, 1, 1.0, _ptr(dprelu), 0, 0, _stream()))
         dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape,
-                                 getattr(ctx, "weight_ref", None))
+                                 getattr(ctx, "weight_ref", None), in_link=ctx.cfg.get("in_link"))
         return dx, dw, db, dprelu, None
 
 
@@ -889,11 +916,14 @@ class MaxPool2(torch.autograd.Function):
     """nn.MaxPool2d(2, 2) on NHWC (VGG19 trunk, utils/GAN.py:24-47)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, *rest):
+        in_link = rest[0] if rest else None               # (optional second argument: the ActLink of the ReLU that produced x)
+        ctx.nin = 1 + len(rest)
         x = x.contiguous()
         n, h, w, cp = x.shape
         y = torch.empty((n, h // 2, w // 2, cp), dtype=x.dtype, device=x.device)
         check(_lib.lib().dsr_maxpool2_fwd(_dt(x), _ptr(x), _ptr(y), n, h, w, cp, _stream()))
+        ctx.in_link = in_link
         ctx.save_for_backward(x)
         return y
 
@@ -902,8 +932,14 @@ class MaxPool2(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         n, h, w, cp = x.shape
         dx = torch.empty_like(x)
-        check(_lib.lib().dsr_maxpool2_bwd(_dt(x), _ptr(x), _ptr(dy.contiguous()), _ptr(dx), n, h, w, cp, _stream()))
-        return dx
+        link = ctx.in_link
+        if link is not None and link.act == ACT_RELU:
+            # x is a ReLU output with this pool as its only consumer: the ReLU's backward rides in the routing (ActLink)
+            check(_lib.lib().dsr_maxpool2_relu_bwd(_dt(x), _ptr(x), _ptr(dy.contiguous()), _ptr(dx), n, h, w, cp, _stream()))
+            link.premasked = True
+        else:
+            check(_lib.lib().dsr_maxpool2_bwd(_dt(x), _ptr(x), _ptr(dy.contiguous()), _ptr(dx), n, h, w, cp, _stream()))
+        return (dx, None) if ctx.nin == 2 else dx
 
 
 class AvgPool2(torch.autograd.Function):

@@ -151,13 +151,21 @@ class Vgg19Loss(nn.Module):
         x = F.ResizeNorm.apply(image, self.tables(image.shape[2], image.shape[3], image.device), self.compute_dtype)
         mods = list(self.net[0].children())
         i = 0
+        # The trunk is a chain: every ReLU output has exactly one consumer (the next conv or a max-pool), whose backward
+        # launch applies that ReLU's mask on its way out (functional.ActLink) -- 15 of the 16 activation-backward passes of
+        # the trunk disappear; the last layer's output feeds the loss and keeps its own.
+        link = None                   # the activation that produced the current x
         while i < len(mods):
             m = mods[i]
             if isinstance(m, nn.Conv2d):
-                x = F.ConvAct.apply(x, m.weight, m.bias, None, dict(stride=1, pad=1, act=F.ACT_RELU))   # conv + ReLU fused
+                out_link = F.ActLink(F.ACT_RELU) if (torch.is_grad_enabled() and F.ACT_LINKS) else None
+                x = F.ConvAct.apply(x, m.weight, m.bias, None,
+                                    dict(stride=1, pad=1, act=F.ACT_RELU, in_link=link, out_link=out_link))   # conv + ReLU fused
+                link = out_link
                 i += 2
             else:
-                x = F.MaxPool2.apply(x)
+                x = F.MaxPool2.apply(x, link)
+                link = None
                 i += 1
         return F.ToNCHW.apply(x, 512)
 

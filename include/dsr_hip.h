@@ -106,6 +106,12 @@ int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const void* dout, 
 /* Which kernel the dispatcher launches for this descriptor (measurement aid: bench.py labels its HIP-event timings
  * with it so they can be matched against rocprofv3's kernel names).  op: 0 forward, 1 dgrad, 2 wgrad.  `e` may be
  * NULL (no statistics, no pixel shuffle, NHWC output).  Returns a static string; never NULL. */
+/* dx = dgrad(dy) * act'(x_act) in one launch: x_act = this conv's own input = the OUTPUT of the activation in front of it
+ * (ReLU, or LeakyReLU with slope > 0); replaces the producing layer's separate activation-backward pass (the VGG19 trunk of
+ * utils/GAN.py:19-57 is a chain of conv + ReLU pairs).  Bit-identical to dsr_conv_dgrad followed by dsr_pw_act_bwd. */
+int dsr_conv_dgrad_masked_supported(const dsr_conv_desc* d);
+int dsr_conv_dgrad_masked(const dsr_conv_desc* d, const void* dy, const void* w_dgrad, const void* x_act, int act, float slope,
+                          void* dx, dsr_stream_t s);
 /* dx = dgrad(dy) + addend in one launch (the gradient of a residual block's input: conv path + skip path,
  * generator.py:24); dsr_conv_dgrad_add_supported tells whether the shape is taken (64 -> 64 3x3 stride 1 zero pad). */
 int dsr_conv_dgrad_add_supported(const dsr_conv_desc* d);
@@ -219,6 +225,9 @@ int dsr_dense2_bwd(int dtype, const float* dout, const float* out, const float* 
 /* nn.MaxPool2d(2,2) of the VGG19 trunk (utils/GAN.py:24,29,38,47); backward routes to the first maximum */
 int dsr_maxpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t s);
 int dsr_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int Cp, dsr_stream_t s);
+/* the same with the backward of the ReLU that produced x folded in (conv + ReLU + MaxPool of the VGG trunk, utils/GAN.py:24-47):
+ * dx = routed dy where the window maximum is > 0 */
+int dsr_maxpool2_relu_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int Cp, dsr_stream_t s);
 /* nn.AvgPool2d(2,2) after a stride-1 conv: downsample_mode='avg' of models/DIP/utils.py:86-94 (floor mode);
  * H, W are the INPUT size of the pool.  downsample_mode='max' uses dsr_maxpool2_* above. */
 int dsr_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, dsr_stream_t s);

@@ -121,6 +121,10 @@ def test_bad_arguments_return_codes_not_crashes(so):
         lambda: lib.dsr_linear_wgrad(0, N, N, N, 32, 8, 64, st),
         lambda: lib.dsr_linear_wgrad_gathered(0, N, N, N, 32, 8, 64, 2, 0.5, st),
         lambda: lib.dsr_clock_sample(N, st),
+        lambda: lib.dsr_conv_dgrad_masked(ctypes.byref(d), N, N, N, L.ACT_RELU, 0.0, N, st),
+        lambda: lib.dsr_conv_dgrad_masked(ctypes.byref(d), one, one, one, L.ACT_LEAKY, 0.0, one, st),     # slope <= 0
+        lambda: lib.dsr_conv_dgrad_masked(ctypes.byref(d), one, one, one, L.ACT_TANH, 0.0, one, st),      # not a sign-type activation
+        lambda: lib.dsr_maxpool2_relu_bwd(0, N, N, N, 1, 4, 4, 8, st),
         lambda: lib.dsr_resample_u8(N, N, 4, 4, 3, 1, 2, N, N, 5, st),
         lambda: lib.dsr_resample_u8(one, one, 4, 4, 3, 2, 2, one, one, 5, st),                # axis
         lambda: lib.dsr_noise_gaussian_u8(N, N, 1, N, 16, st),

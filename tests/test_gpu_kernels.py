@@ -724,3 +724,58 @@ def test_conv_dgrad_add_equals_dgrad_then_add(dev):
     assert torch.isfinite(dx1.float()).all() and torch.equal(ref, dx1)
     bad = L.ConvDesc(L.BF16, n, h, w, 64, 128, 3, 3, 1, 1, 0)
     assert lib.dsr_conv_dgrad_add(C.byref(bad), dy.data_ptr(), wd.data_ptr(), add.data_ptr(), dx1.data_ptr(), st) < 0
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 37, 70, 64, 64), (2, 28, 28, 128, 128), (3, 20, 24, 256, 512), (2, 30, 42, 64, 128),
+                                          (1, 14, 14, 512, 512)])
+def test_conv_dgrad_masked_equals_dgrad_then_act_bwd(dev, n, h, w, cin, cout):
+    """dsr_conv_dgrad_masked (the ReLU / LeakyReLU backward of the layer in front folded into the input-gradient store loop;
+    the conv + ReLU chain of utils/GAN.py:19-57) against dsr_conv_dgrad followed by dsr_pw_act_bwd: the same fp32 product on
+    the same rounded values => BIT FOR BIT, on the 64->64 kernel (residual-prefetch mode) and the 128x64 / 128x128 / 256x256
+    tiles of the gather kernel, ragged sizes included."""
+    import ctypes as C
+    L = P("_lib")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = L.ConvDesc(L.BF16, n, h, w, cin, cout, 3, 3, 1, 1, 0)
+    assert lib.dsr_conv_dgrad_masked_supported(C.byref(d)) == 1
+    g = torch.Generator(device="cpu").manual_seed(31)
+    wt = ((torch.rand(cout, cin, 3, 3, generator=g) - 0.5) * 0.1).to(dev)
+    wf = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 0), dtype=torch.bfloat16, device=dev)
+    wd = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 1), dtype=torch.bfloat16, device=dev)
+    L.check(lib.dsr_conv_pack_weight(C.byref(d), wt.data_ptr(), wf.data_ptr(), wd.data_ptr(), st))
+    dy = (torch.rand(n, h, w, cout, generator=g) - 0.5).to(torch.bfloat16).to(dev)
+    x = torch.relu(torch.rand(n, h, w, cin, generator=g) - 0.4).to(torch.bfloat16).to(dev)      # a ReLU output: ~40 % zeros
+    for act, slope in ((L.ACT_RELU, 0.0), (L.ACT_LEAKY, 0.2)):
+        xa = x if act == L.ACT_RELU else (x - 0.05 * (x == 0)).to(torch.bfloat16)              # Leaky outputs: negatives where it was zero
+        dx0 = torch.empty_like(x)
+        L.check(lib.dsr_conv_dgrad(C.byref(d), dy.data_ptr(), wd.data_ptr(), dx0.data_ptr(), None, 0, st))
+        ref = torch.empty_like(x)
+        L.check(lib.dsr_pw_act_bwd(L.BF16, dx0.data_ptr(), xa.data_ptr(), ref.data_ptr(), n, h, w, cin, cin, 0, act, slope, None, 1,
+                                   n * h * w, None, st))
+        got = torch.full_like(x, float("nan"))
+        L.check(lib.dsr_conv_dgrad_masked(C.byref(d), dy.data_ptr(), wd.data_ptr(), xa.data_ptr(), act, slope, got.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert torch.isfinite(got.float()).all() and torch.equal(ref, got), (act, slope)
+    assert lib.dsr_conv_dgrad_masked(C.byref(d), dy.data_ptr(), wd.data_ptr(), x.data_ptr(), L.ACT_LEAKY, -0.1, got.data_ptr(), st) < 0
+    s2 = L.ConvDesc(L.BF16, n, h - h % 2, w - w % 2, cin, cout, 3, 3, 2, 1, 0)
+    assert lib.dsr_conv_dgrad_masked_supported(C.byref(s2)) == 0
+
+
+def test_maxpool_relu_bwd_equals_pool_bwd_then_mask(dev):
+    """dsr_maxpool2_relu_bwd (conv + ReLU + MaxPool of the VGG trunk) == dsr_maxpool2_bwd followed by the ReLU mask, bit for bit,
+    including windows whose four inputs are all zero (gradient dropped) and ties."""
+    import ctypes as C
+    L = P("_lib")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cpu").manual_seed(33)
+    n, h, w, c = 2, 18, 26, 64
+    x = torch.relu(torch.rand(n, h, w, c, generator=g) - 0.7).to(torch.bfloat16).to(dev)       # 70 % zeros: many all-zero windows
+    dy = (torch.rand(n, h // 2, w // 2, c, generator=g) - 0.5).to(torch.bfloat16).to(dev)
+    a, b = torch.empty_like(x), torch.full_like(x, float("nan"))
+    L.check(lib.dsr_maxpool2_bwd(L.BF16, x.data_ptr(), dy.data_ptr(), a.data_ptr(), n, h, w, c, st))
+    L.check(lib.dsr_maxpool2_relu_bwd(L.BF16, x.data_ptr(), dy.data_ptr(), b.data_ptr(), n, h, w, c, st))
+    torch.cuda.synchronize()
+    assert torch.equal(a * (x > 0), b)
+    assert float((a != b).float().mean()) > 0.01        # (the mask does something on this input)

@@ -893,3 +893,25 @@ def test_batched_wgrad_leaves_existing_grad_and_exceptions_alone(dev):
         with F.batched_wgrad():
             1 / 0
     assert F._wgrad_batch is None
+
+
+def test_vgg_trunk_act_links_equal_separate_passes(dev):
+    """utils.GAN.Vgg19Loss with functional.ActLink (every ReLU's backward folded into its consumer's input-gradient / max-pool
+    backward launch) against the same trunk with one activation-backward pass per layer: loss and image gradient bit for bit."""
+    GANu, F = P("utils.GAN"), P("functional")
+    loss_mod = GANu.Vgg19Loss().to(dev)
+    img = filler.tensor("in:vl_a", (2, 3, 96, 96)).to(dev)
+    tgt = filler.tensor("in:vl_b", (2, 3, 96, 96)).to(dev)
+    res = []
+    try:
+        for links in (False, True):
+            F.ACT_LINKS = links
+            a = img.clone().requires_grad_(True)
+            loss = loss_mod(a, tgt)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((loss.detach().clone(), a.grad.clone()))
+    finally:
+        F.ACT_LINKS = True
+    assert torch.isfinite(res[1][1]).all() and float(res[1][1].abs().max()) > 0
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
