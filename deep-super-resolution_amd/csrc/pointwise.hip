@@ -269,48 +269,57 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int tiles,
 #define DSR_FINALIZE_PAR_ROWS 512      // measured (a sweep over the row count): one launch wins up to ~512 rows (6.6 us vs ~10 us for
                                        // compaction + finalize); at 2048 rows its latency chain loses (18.6 us vs 8 us)
 #define DSR_FINALIZE_PAR_ROWS_BWD 64   // three slices per row: loses from 512 rows on (36.7 us)
-template <int NS>
+// CW channels x (256 / CW) row-lanes per block: with CW = 16 a 64-channel layer is summed by four blocks of 16 lanes each
+// (512 rows = 32 per lane = four rounds of 8 loads) instead of one block whose 4 lanes walk 128 rows each (16 rounds: the
+// 9.8 us of the single-block form were that load chain).
+template <int NS, int CW>
 __device__ __forceinline__ void par_column_sums(const float* __restrict__ partial, int rows, int row_stride, int slice_stride,
-                                                int c, bool active, double (&tot)[NS], double* red /* [NS][4][64] */) {
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+                                                int c, bool active, double (&tot)[NS], double* red /* [NS][256 / CW][CW] */) {
+  constexpr int LANES = 256 / CW;
+  const int cx = threadIdx.x % CW, ry = threadIdx.x / CW;
   double s[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) s[k] = 0.0;
   if (active) {
     int r = ry;
-    for (; r + 28 < rows; r += 32) {
+    for (; r + 7 * LANES < rows; r += 8 * LANES) {
       float v[NS][8];
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int k = 0; k < NS; ++k) v[k][u] = partial[(size_t)(r + 4 * u) * row_stride + k * slice_stride + c];
+        for (int k = 0; k < NS; ++k) v[k][u] = partial[(size_t)(r + LANES * u) * row_stride + k * slice_stride + c];
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int k = 0; k < NS; ++k) s[k] += (double)v[k][u];
     }
-    for (; r < rows; r += 4)
+    for (; r < rows; r += LANES)
 #pragma unroll
       for (int k = 0; k < NS; ++k) s[k] += (double)partial[(size_t)r * row_stride + k * slice_stride + c];
   }
 #pragma unroll
-  for (int k = 0; k < NS; ++k) red[(k * 4 + ry) * 64 + cx] = s[k];
+  for (int k = 0; k < NS; ++k) red[(k * LANES + ry) * CW + cx] = s[k];
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < NS; ++k)
-    tot[k] = red[(k * 4 + 0) * 64 + cx] + red[(k * 4 + 1) * 64 + cx] + red[(k * 4 + 2) * 64 + cx] + red[(k * 4 + 3) * 64 + cx];
+  for (int k = 0; k < NS; ++k) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < LANES; ++q) t += red[(k * LANES + q) * CW + cx];      // fixed order: deterministic
+    tot[k] = t;
+  }
 }
 
+template <int CW>
 __global__ __launch_bounds__(256) void bn_finalize_par_kernel(
     const float* __restrict__ partial, int tiles, int stride, int C, float count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
     long long* __restrict__ num_batches, float momentum, float eps, int updates, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ rstd_out, int Cp) {
-  __shared__ double red[2 * 4 * 64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  __shared__ double red[2 * 256];
+  const int c = blockIdx.x * CW + (threadIdx.x % CW);
   double tot[2];
-  par_column_sums<2>(partial, tiles, 2 * stride, stride, c, c < C, tot, red);
-  if (threadIdx.x >= 64 || c >= Cp) return;
+  par_column_sums<2, CW>(partial, tiles, 2 * stride, stride, c, c < C, tot, red);
+  if (threadIdx.x >= CW || c >= Cp) return;
   if (c >= C) {   // padded channels
     scale[c] = 0.f;
     shift[c] = 0.f;
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_par_kernel(const float* _
   const int cx = threadIdx.x & 63;
   const int c = blockIdx.x * 64 + cx;
   double tot[3];
-  par_column_sums<3>(partial, blocks, 3 * Cp, Cp, c, c < Cp, tot, red);
+  par_column_sums<3, 64>(partial, blocks, 3 * Cp, Cp, c, c < Cp, tot, red);
   if (threadIdx.x < 64 && c < Cp) {
     if (c < C) tot[1] = (double)rstd[c] * (tot[1] - (double)mean[c] * tot[0]);      // sum g*y -> sum g*xhat
     if (c < C) {
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(256) void sum_rows_par_kernel(const float* __restri
   __shared__ double red[4 * 64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   double tot[1];
-  par_column_sums<1>(partial + col_offset, rows, row_stride, 0, c, c < C, tot, red);
+  par_column_sums<1, 64>(partial + col_offset, rows, row_stride, 0, c, c < C, tot, red);
   if (threadIdx.x >= 64 || c >= C) return;
   const float v = (float)(tot[0] * (double)scale);
   out[c] = accumulate ? out[c] + v : v;
@@ -1084,8 +1093,13 @@ extern "C" int dsr_pw_bn_finalize(const float* partial, int tiles, int stride, i
                         float* scale, float* shift, float* mean, float* rstd, hipStream_t st) {
   DSR_REQUIRE(partial && gamma && beta && scale && shift && mean && rstd && tiles > 0 && C > 0 && Cp >= C && stride >= Cp && count > 0.f && updates >= 0, "bn_finalize: null pointer or bad shape");
   if (tiles > 32 && tiles <= DSR_FINALIZE_PAR_ROWS) {
-    hipLaunchKernelGGL(bn_finalize_par_kernel, dim3(nblk(Cp, 64)), dim3(256), 0, st, partial, tiles, stride, C, count, gamma, beta,
-                       rm, rv, nbt, momentum, eps, updates, scale, shift, mean, rstd, Cp);
+    // 16 channels per block (16 row-lanes) once there are enough rows to share out; 64 channels x 4 lanes for short tables
+    if (tiles > 128 && Cp % 16 == 0)
+      hipLaunchKernelGGL(bn_finalize_par_kernel<16>, dim3(nblk(Cp, 16)), dim3(256), 0, st, partial, tiles, stride, C, count, gamma,
+                         beta, rm, rv, nbt, momentum, eps, updates, scale, shift, mean, rstd, Cp);
+    else
+      hipLaunchKernelGGL(bn_finalize_par_kernel<64>, dim3(nblk(Cp, 64)), dim3(256), 0, st, partial, tiles, stride, C, count, gamma,
+                         beta, rm, rv, nbt, momentum, eps, updates, scale, shift, mean, rstd, Cp);
     return dsr_launch_status("dsr_pw_bn_finalize");
   }
   partial = compact_rows(partial, tiles, 2 * stride, &tiles, st);
