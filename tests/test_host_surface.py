@@ -244,3 +244,40 @@ def test_perceptual_loss_accepts_local_vgg_state_dict():
     with pytest.raises(RuntimeError):
         G.PerceptualLoss(vgg_state_dict=bad)
     assert not G.PerceptualLoss().vgg_loss.pretrained
+
+
+def test_data_host_logic_matches_oracle():
+    """Host-side pieces of the data path (no GPU): the product's Pillow coefficient tables (utils/degradation.resample_tables,
+    what the HIP resampler is fed) against the oracle's restatement of Pillow's precompute_coeffs / normalize_coeffs_8bpc, and
+    the patch sampler against dataset.py:121-147 as restated in the oracle."""
+    import numpy as np
+    from oracle import data as od
+    D, DS = P("utils.degradation"), P("dataset")
+    for n_in, n_out in [(124, 62), (90, 45), (53, 37), (31, 124), (2040, 1020), (339, 255)]:
+        ksize, bounds, kk = D.resample_tables(n_in, n_out, "cpu")
+        rk, rb, rkk = od.resample_coeffs(n_in, n_out)
+        assert ksize == rk and np.array_equal(bounds.numpy(), rb) and np.array_equal(kk.numpy(), rkk), (n_in, n_out)
+        assert int(kk.sum(1).min()) > (1 << 22) - 64 and int(kk.sum(1).max()) < (1 << 22) + 64      # weights sum to ~1.0 in 22-bit fixed point
+    a, b = np.random.RandomState(9), np.random.RandomState(9)
+    for _ in range(50):
+        assert DS.train_patch_coords(170, 255, (128, 96), 4, a) == od.train_patch_coords(170, 255, 128, 96, 4, b)
+
+
+def test_act_link_and_batched_wgrad_contexts_without_gpu():
+    """functional.ActLink is a plain hand-over cell; functional.batched_wgrad is re-entrant-safe bookkeeping: an empty block
+    launches nothing, a nested block defers to the outer one, an exception discards the batch."""
+    F = P("functional")
+    link = F.ActLink(F.ACT_RELU)
+    assert (link.act, link.slope, link.premasked) == (F.ACT_RELU, 0.0, False)
+    with F.batched_wgrad() as outer:
+        assert F._wgrad_batch is outer
+        with F.batched_wgrad() as inner:
+            assert F._wgrad_batch is outer and inner is not outer
+        assert F._wgrad_batch is outer
+    assert F._wgrad_batch is None
+    with F.batched_wgrad(False) as off:
+        assert F._wgrad_batch is None and off.items == {}
+    with pytest.raises(KeyError):
+        with F.batched_wgrad():
+            raise KeyError("x")
+    assert F._wgrad_batch is None
