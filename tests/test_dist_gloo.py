@@ -104,6 +104,9 @@ def _factor_worker(rank, world, port, q):
     w2.grad = torch.full((o, k), float(rank + 1))
     sync()
     ok = ok and torch.equal(w2.grad, torch.full((o, k), float(rank + 1)))
+    # optim.FusedAdam(fuse_dense_head=True) keeps dense1's gradient as a factor pair only when nobody will all-reduce it:
+    # a globally produced gradient (w2) may stay factored, a plain one (w1: GradSync averages it after backward) may not
+    ok = ok and F._awaits_allreduce(w1) and not F._awaits_allreduce(w2)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -129,3 +132,5 @@ def test_grad_sync_noop_single_process():
     p.grad = torch.ones(3)
     D.GradSync([p])()
     assert torch.equal(p.grad, torch.ones(3)) and not D.is_dist()
+    F = importlib.import_module(PKG + ".functional")
+    assert not F._awaits_allreduce(p)            # one process: nothing to average, the dense gradient may stay factored
