@@ -518,7 +518,9 @@ def main():
     c = clk.cpu().tolist()
     per_xcd = [(c[16 + 2 * x] - c[2 * x]) / (c[17 + 2 * x] - c[1 + 2 * x]) * 0.1            # cycles per 10 ns tick
                for x in range(8) if c[1 + 2 * x] and c[17 + 2 * x] > c[1 + 2 * x]]
-    shader_ghz = sum(per_xcd) / len(per_xcd) if per_xcd else 0.0
+    # (the cycle counters of different CUs are not synchronised: the two samples of an XCD may come from different CUs, a
+    #  constant offset that only washes out over a long region -- below 0.2 s the figure is not reported)
+    shader_ghz = sum(per_xcd) / len(per_xcd) if (per_xcd and dt >= 0.2) else None
     wait_ms = sum(sy.pop_wait_ms() for sy in syncs) / a.steps
     for sy in syncs:
         sy.timing = False
@@ -561,7 +563,7 @@ def main():
            "hip_graph": bool(isinstance(step, _Callable)),
            # average shader clock over the timed steps (s_memtime / s_memrealtime): the chip lowers it under load, so a
            # fraction of the 2.5 PFLOP/s nominal peak (2.4 GHz) is really measured against peak * clock / 2.4
-           "avg_shader_clock_ghz": round(shader_ghz, 3)}
+           "avg_shader_clock_ghz": None if shader_ghz is None else round(shader_ghz, 3)}
     if world > 1 or force:
         out["collective_wait_ms_per_step"] = wait_all
 
