@@ -32,7 +32,7 @@ struct ConvGemmLds {
 };
 
 template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA, int NSTAGE, bool SWAP>
-__global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 256 * 256) ? (WGM * WGN >= 8 ? 2 : 1) : (WGM * WGN) / 2) void conv_gemm_kernel(const ConvGemmArgs a) {
+__global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 256 * 256) ? 2 : (WGM * WGN) / 2) void conv_gemm_kernel(const ConvGemmArgs a) {
   static_assert(!DMA || FAST, "the LDS-DMA loader exists for the fast path only");
   static_assert(NSTAGE == 2 || (NSTAGE == 3 && DMA), "three stages: DMA ring only");
   constexpr int NW = WGM * WGN;                 // 4 or 8 waves; two blocks per CU either way
@@ -783,10 +783,7 @@ static void dispatch_dt(const ConvGemmArgs& a, hipStream_t st) {
     // (0.375 ds_read_b128 per MFMA instead of 0.5) and half the DMA pieces of the 128x128 tile
     const int big_mode = dsr_conv_big_mode();
     if (dsr_conv_gemm_use_256(a.M, a.NB, fast && env_on("DSR_CONV_DMA"), (a.flags & DSR_F_STATS) != 0))
-      if (big_mode == 3)
-        launch_one<DT, 256, 256, 2, 2>(a, st);     // experiment: 4 waves of 128x128, one wave per SIMD, 512 registers
-      else
-        launch_one<DT, 256, 256, 2, 4>(a, st);
+      launch_one<DT, 256, 256, 2, 4>(a, st);
     else if (use_big && big_mode == 1 && fast && big_tiles >= 512)
       launch_one<DT, 256, 128, 4, 2, 3>(a, st);
     else

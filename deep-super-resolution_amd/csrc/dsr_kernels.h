@@ -78,7 +78,7 @@ static inline bool dsr_conv_gemm_use_256(long long M, int NB, bool fast, bool st
   const long long tiles = ((M + 255) / 256) * ((NB + 255) / 256);
   (void)stats;   // both epilogues exist on the 256x256 tile (statistics from the channel-major accumulators)
   const char* t = getenv("DSR_CONV_BIG_TILES");      // tuning switch: fewest 256x256 tiles worth taking (default 150: a 196-tile launch on 256 CUs still beats four times as many 128x128 tiles, measured on VGG 512->512 at 28x28)
-  return dsr_conv_big_mode() >= 2 && fast && NB % 256 == 0 && tiles >= (t ? atoi(t) : 150);
+  return dsr_conv_big_mode() == 2 && fast && NB % 256 == 0 && tiles >= (t ? atoi(t) : 150);
 }
 
 bool dsr_launch_conv_gemm_persist(const ConvGemmArgs& a, int dtype, hipStream_t st);   // conv_gemm_persist.hip
