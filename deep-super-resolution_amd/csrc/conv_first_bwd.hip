@@ -10,6 +10,8 @@
 //   * issues 8 MFMAs per wave (both operands by transposing LDS reads, as in the other weight-gradient kernels).
 // It reads dout and y once (2 x 128 B per pixel) and nothing else of that size; the old path (act_bwd + colsum +
 // wgrad) moved 5 such tensors.  Deterministic: one partial [64][32] per block, folded by first_bwd_finalize_kernel.
+#include <stdlib.h>
+
 #include "../../include/dsr_hip.h"
 #include "dsr_common.h"
 #include "dsr_kernels.h"
@@ -27,12 +29,14 @@ __device__ __forceinline__ s16x4 fb_tr_read(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
-template <int DT>
-__global__ __launch_bounds__(256, 2) void conv_first_bwd_kernel(const FirstBwdArgs a) {
+// NS = 2: two stages, the next tile's DMA under this tile's work, two blocks per CU (74 KB).  NS = 1: one stage, FOUR blocks
+// per CU (37 KB): a tile's phases are short dependent LDS round trips between barriers, so what hides them is more resident
+// waves, and the other three blocks cover a block's DMA wait as well as a second stage would.
+template <int DT, int NS>
+__global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_first_bwd_kernel(const FirstBwdArgs a) {
   // stage s: [dout tile | y tile | image halo]; the im2col image is built over the y tile once g has been formed
-  // (74 KB in all: two blocks per CU)
   static_assert(FB_B <= FB_T, "im2col image must fit in the y tile");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FB_STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * FB_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
@@ -77,13 +81,18 @@ __global__ __launch_bounds__(256, 2) void conv_first_bwd_kernel(const FirstBwdAr
   f32x4 acc[2];
   acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
   int t = blockIdx.x;
-  if (t < a.ntiles) dma(t, 0);
+  if (NS == 2 && t < a.ntiles) dma(t, 0);
   int buf = 0;
-  for (; t < a.ntiles; t += gridDim.x, buf ^= 1) {
+  for (; t < a.ntiles; t += gridDim.x, buf ^= (NS - 1)) {
+    if constexpr (NS == 1) {
+      __builtin_amdgcn_s_barrier();                                  // every wave is done with the previous tile
+      asm volatile("" ::: "memory");
+      dma(t, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                    // this tile landed; the previous step's reads are done
     asm volatile("" ::: "memory");
-    if (t + (int)gridDim.x < a.ntiles) dma(t + gridDim.x, buf ^ 1);
+    if (NS == 2 && t + (int)gridDim.x < a.ntiles) dma(t + gridDim.x, buf ^ 1);
     unsigned char* st = smem + buf * FB_STAGE;
     // ---- g = dout * act'(y), in place (4 chunks per thread; slot (p, pos) holds channel chunk pos ^ (p & 7) in both tiles)
 #pragma unroll
@@ -161,22 +170,28 @@ __global__ __launch_bounds__(256, 2) void conv_first_bwd_kernel(const FirstBwdAr
     for (int j = 0; j < 4; ++j) P[(16 * wave + 4 * g + j) * 32 + 16 * nf + l16] = acc[nf][j];
 }
 
-// dw[co][ci][tap] (OIHW, fp32) and db[co] from the per-block partials (fixed order: deterministic)
-__global__ void first_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int Cin, float* __restrict__ dw,
-                                          float* __restrict__ db) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;            // (co, col)
-  if (idx >= 64 * 32) return;
-  const int co = idx >> 5, col = idx & 31;
+// dw[co][ci][tap] (OIHW, fp32) and db[co] from the per-block partials (fixed order: deterministic).  One block per output
+// channel: thread (r, col) adds the rows r, r + 8, ... of its column in double, the 8 row classes are folded in order.
+__global__ __launch_bounds__(256) void first_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int Cin,
+                                                                 float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ double part[8][32];
+  const int co = blockIdx.x, r = threadIdx.x >> 5, col = threadIdx.x & 31;
+  const float* src = partial + co * 32 + col;
   double s = 0.0;
-  int b = 0;
-  for (; b + 8 <= blocks; b += 8) {
+  int b = r;
+  for (; b + 56 < blocks; b += 64) {
     float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + u) * 2048 + idx];
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(b + 8 * u) * 2048];
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += (double)v[u];
   }
-  for (; b < blocks; ++b) s += (double)partial[(size_t)b * 2048 + idx];
+  for (; b < blocks; b += 8) s += (double)src[(size_t)b * 2048];
+  part[r][col] = s;
+  __syncthreads();
+  if (r != 0) return;
+#pragma unroll
+  for (int q = 1; q < 8; ++q) s += part[q][col];
   if (col < 27) {
     const int tap = col / 3, ci = col - 3 * tap;
     if (ci < Cin) dw[((size_t)co * Cin + ci) * 9 + tap] = (float)s;
@@ -185,7 +200,11 @@ __global__ void first_bwd_finalize_kernel(const float* __restrict__ partial, int
   }
 }
 
-static int first_bwd_blocks(long long ntiles) { return (int)(ntiles < 512 ? ntiles : 512); }
+static int first_bwd_stages() {          // tuning switch DSR_FIRST_BWD_STAGES: 1 (default) | 2
+  const char* e = getenv("DSR_FIRST_BWD_STAGES");
+  return (e && e[0] == '2') ? 2 : 1;
+}
+static int first_bwd_blocks(long long ntiles) { return (int)(ntiles < 1024 ? ntiles : 1024); }   // (four resident blocks per CU)
 
 extern "C" size_t dsr_conv_first_bwd_workspace(const dsr_conv_desc* d) {
   if (!d) return 0;
@@ -223,10 +242,18 @@ extern "C" int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const v
   a.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * 16);
   a.y_bytes = (unsigned)((size_t)d->N * d->H * d->W * 128);
   const int blocks = first_bwd_blocks(a.ntiles);
-  if (d->dtype == DSR_BF16)
-    hipLaunchKernelGGL((conv_first_bwd_kernel<DSR_DTYPE_BF16>), dim3(blocks), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((conv_first_bwd_kernel<DSR_DTYPE_F16>), dim3(blocks), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(first_bwd_finalize_kernel, dim3(8), dim3(256), 0, s, (const float*)workspace, blocks, d->Cin, dw, db);
+  const bool two = first_bwd_stages() == 2;
+  if (d->dtype == DSR_BF16) {
+    if (two)
+      hipLaunchKernelGGL((conv_first_bwd_kernel<DSR_DTYPE_BF16, 2>), dim3(blocks), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((conv_first_bwd_kernel<DSR_DTYPE_BF16, 1>), dim3(blocks), dim3(256), 0, s, a);
+  } else {
+    if (two)
+      hipLaunchKernelGGL((conv_first_bwd_kernel<DSR_DTYPE_F16, 2>), dim3(blocks), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((conv_first_bwd_kernel<DSR_DTYPE_F16, 1>), dim3(blocks), dim3(256), 0, s, a);
+  }
+  hipLaunchKernelGGL(first_bwd_finalize_kernel, dim3(64), dim3(256), 0, s, (const float*)workspace, blocks, d->Cin, dw, db);
   return dsr_launch_status("dsr_conv_first_bwd");
 }

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Timing of dsr_conv_first_bwd (the discriminator's first layer at config 3: 32 x 512 x 512, 3 -> 64; GPU box only,
+development aid).  Algorithmic bytes: the upstream gradient and the layer's output, 128 B per pixel each."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+L = importlib.import_module("deep-super-resolution_amd._lib")
+
+
+def main():
+    dev = torch.device("cuda:0")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n, h, w in ((32, 512, 512), (32, 224, 224), (8, 128, 128)):
+        d = L.ConvDesc(L.BF16, n, h, w, 3, 64, 3, 3, 1, 1, 0)
+        x = torch.rand(n, h, w, 8, device=dev).to(torch.bfloat16)
+        x[..., 3:] = 0
+        dout = (torch.rand(n, h, w, 64, device=dev) - 0.5).to(torch.bfloat16)
+        y = (torch.rand(n, h, w, 64, device=dev) - 0.5).to(torch.bfloat16)
+        dw = torch.empty(64, 3, 3, 3, device=dev)
+        db = torch.empty(64, device=dev)
+        wsb = lib.dsr_conv_first_bwd_workspace(C.byref(d))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+
+        def run():
+            L.check(lib.dsr_conv_first_bwd(C.byref(d), x.data_ptr(), dout.data_ptr(), y.data_ptr(), 1, 0.2, dw.data_ptr(),
+                                           db.data_ptr(), ws.data_ptr(), wsb, st))
+
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        gb = n * h * w * 256 / 1e9
+        print(f"first_bwd {n} x {h} x {w}: {ms*1e3:8.1f} us   {gb/ms:6.2f} TB/s of dout + y   |dw| {float(dw.abs().sum()):.4e}")
+
+
+if __name__ == "__main__":
+    main()
