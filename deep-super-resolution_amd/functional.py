@@ -509,9 +509,24 @@ class ConvBNAct(torch.autograd.Function):
                                          int(cfg.get("bn_updates", 1)),
                                          _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
         else:
-            check(lib.dsr_pw_bn_eval_affine(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), BN_EPS,
-                                            cout, cp, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
-            if cfg.get("infer", False) and lib.dsr_conv_fwd_affine_supported(C.byref(desc)):
+            infer = cfg.get("infer", False) and lib.dsr_conv_fwd_affine_supported(C.byref(desc))
+            # inference: the affine map of an eval-mode BatchNorm changes only when its four tensors do -- keep it with the
+            # running mean, keyed by their version counters (33 launches of ~3 us per x8 forward otherwise)
+            key = (gamma._version, beta._version, running_mean._version, running_var._version, str(dev))
+            hit = getattr(running_mean, "_dsr_affine", None) if infer else None
+            capturing = torch.cuda.is_current_stream_capturing()
+            if hit is not None and hit[0] == key:
+                scale, shift = hit[1], hit[2]
+                if hit[4] != torch.cuda.current_stream(dev).cuda_stream and not capturing:
+                    torch.cuda.current_stream(dev).wait_event(hit[3])      # computed on another stream
+            else:
+                check(lib.dsr_pw_bn_eval_affine(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), BN_EPS,
+                                                cout, cp, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
+                if infer and not capturing:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    running_mean._dsr_affine = (key, scale, shift, ev, torch.cuda.current_stream(dev).cuda_stream)
+            if infer:
                 # inference (eval_GAN.py:44,94; called under torch.no_grad(), see apply() below): eval-mode BatchNorm
                 # is a fixed per-channel affine map, so it, the activation and the skip connection all ride in the conv
                 # epilogue -- one kernel, one pass

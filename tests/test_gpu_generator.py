@@ -143,6 +143,31 @@ def test_generator_fp16_inference(dev):
     assert (y.cpu() - yr).abs().max().item() <= 0.02          # fp16 has 3 more mantissa bits than bf16
 
 
+def test_inference_affine_cache_follows_the_statistics(dev):
+    """eval-mode BatchNorm is folded into the conv epilogue as a per-channel affine map that is kept between forwards
+    (functional.ConvBNAct): a second forward reuses it bit for bit, an in-place change of the running statistics (what
+    load_state_dict does) or of gamma must be seen by the next forward."""
+    g, sd = build(dev, 4, 2)
+    g.eval()
+    x = filler.tensor("in:gen_cache", (1, 3, 24, 24), 0.5, 0.5).to(dev)
+    with torch.no_grad():
+        y0 = g(x)
+        y1 = g(x)
+        assert torch.equal(y0, y1)
+        bn = g.residual_blocks[0].bn1
+        assert getattr(bn.running_mean, "_dsr_affine", None) is not None
+        bn.running_var.mul_(4.0)
+        bn.weight.mul_(0.5)
+        y2 = g(x)
+    torch.cuda.synchronize()
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["residual_blocks.0.bn1.running_var"] *= 4.0
+    sd2["residual_blocks.0.bn1.weight"] *= 0.5
+    yr = gan.generator_forward(sd2, x.cpu(), False)
+    assert not torch.equal(y2, y0)
+    assert (y2.cpu() - yr).abs().max().item() <= 0.06
+
+
 def test_gen_l1_trajectory(dev):
     """BASELINE config-2 step recipe: 4 Adam steps, PSNR delta vs the fp32 oracle <= 0.02 dB."""
     optim, steps = P("optim"), P("steps")
