@@ -39,7 +39,7 @@ __device__ __forceinline__ float vmax(float a, float b) {
 // 2: swapped + FOLD, the inference epilogue (eval-mode BatchNorm scale/shift, residual); 3: swapped + residual only, with
 // the residual tile REQUESTED AT THE TOP of the tile, in front of the next tile's DMA (dsr_conv_dgrad_add: vmcnt retires in
 // order, so a load issued in the epilogue would wait for that DMA -- measured 82 us per trunk dgrad against 42 + 32 us for
-// dgrad and a separate add; mode 2 has no registers left for the prefetch).  Separate instantiations: the
+// dgrad and a separate add; mode 2 does the same since its scale / shift moved to LDS).  Separate instantiations: the
 // layouts need different per-lane constants and the kernel has no registers to spare.
 // Tile = TR rows x 32 columns.  A wave owns a 16-COLUMN strip (wq) of all TR rows and a 32-channel half (wc): its m-tiles are
 // the tile's rows.  An A fragment (16 pixels of one halo row at one tap column) then serves up to three output rows
@@ -72,21 +72,11 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   // weight rows of each 16-channel tile are taken in the order m -> 4 (m & 3) + (m >> 2), so that those 4 values are
   // the 4 consecutive output channels of ONE sub-pixel (conv channel 4c + s -> sub-pixel s, channel c).
   constexpr bool FOLD = MODE == 2;
-  constexpr bool RES_EARLY = MODE == 3;
+  constexpr bool RES_EARLY = MODE == 3 || MODE == 2;   // residual tile requested at the top of the tile (see above)
   constexpr bool swp = MODE != 0;
   const bool do_stats = MODE == 0 && (a.flags & DSR_F_STATS) != 0;
   const bool pixshuf = (a.flags & DSR_F_PIXSHUF) != 0;
   const int wrow = (swp && pixshuf) ? 4 * (r16 & 3) + (r16 >> 2) : r16;
-  // ---- weights: registers, once (rows = output channels wc*32 + nt*16 + wrow)
-  U4 fw[9][2][2];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-        fw[t][kk][nt] = *reinterpret_cast<const U4*>(W + ((size_t)(t * a.CoutP + c0 + wc * 32 + nt * 16 + wrow)) * 64 + kk * 32 + g * 8);
-
   // A-fragment LDS offsets: halo column (16 wq + tx + r16) -> *128 + swizzled chunk (key = column & 7); + halo row * HC * 128
   int lds_off[3][2];
 #pragma unroll
@@ -181,6 +171,22 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     }
   };
 
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tstep = gridDim.x;
+  TileXY cur = decomp(t), nxt = advance(cur);
+  if (t < a.ntiles) fetch(cur, 0);
+  // ---- weights: registers, once (rows = output channels wc*32 + nt*16 + wrow).  Requested BEHIND the first tile's DMA, so
+  // that the two latencies overlap (a launch of a few tiles per block -- the x8 inference trunk, config 2 -- is mostly this prologue)
+  asm volatile("" ::: "memory");
+  U4 fw[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        fw[t][kk][nt] = *reinterpret_cast<const U4*>(W + ((size_t)(t * a.CoutP + c0 + wc * 32 + nt * 16 + wrow)) * 64 + kk * 32 + g * 8);
+
   const float slope = (a.flags & DSR_F_PRELU_PTR) ? a.prelu[0] : a.slope;
   // channel of accumulator register r of n-tile nt: pixel-major layout: wc*32 + nt*16 + r16 (all r);
   // swapped: wc*32 + nt*16 + (4g + r), through the PixelShuffle row order: wc*32 + nt*16 + 4r + g
@@ -188,11 +194,25 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     return wc * 32 + nt * 16 + (!swp ? r16 : (pixshuf ? 4 * r + g : 4 * g + r));
   };
   constexpr int NB = swp ? 4 : 1;              // distinct channels among a lane's 4 accumulator registers
+  // (FOLD launches keep no bias registers: the bias is folded into the shift of the affine map, see below)
   float bias_v[2][NB];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int r = 0; r < NB; ++r) bias_v[nt][r] = (a.flags & DSR_F_BIAS) ? a.bias[c0 + chan(nt, r)] : 0.f;
+    for (int r = 0; r < NB; ++r) bias_v[nt][r] = (!FOLD && (a.flags & DSR_F_BIAS)) ? a.bias[c0 + chan(nt, r)] : 0.f;
+  if constexpr (FOLD) {
+    // inference: eval-mode BatchNorm folded in, y = act((conv + bias) * scale + shift) = act(conv * scale + shift') with
+    // shift' = shift + bias * scale.  The per-channel pair lives in the (otherwise unused) statistics area of LDS: a load
+    // from global memory in the epilogue would wait, in order, for the next tile's DMA.  Visible to
+    // every wave after the first tile's barrier.
+    if (tid < 64) {
+      const bool aff = (a.flags & DSR_F_AFFINE) != 0;
+      const float sc = aff ? a.scale[c0 + tid] : 1.f;
+      const float bv = (a.flags & DSR_F_BIAS) ? a.bias[c0 + tid] : 0.f;
+      sStat[0][0][tid] = sc;
+      sStat[0][1][tid] = __builtin_fmaf(bv, sc, aff ? a.shift[c0 + tid] : 0.f);
+    }
+  }
 
   // C tile in LDS: pixel rows of 64 channels.  PixelShuffle(2) launches store channel 4c + s at byte s*32 + c*2, i.e.
   // already grouped by sub-pixel, so that the store loop reads whole 16-byte vectors in both layouts.
@@ -219,10 +239,6 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     st_step = 2 * (2 * a.W) * OCp * 2;                                 // conv row + 1 = output rows + 2
   }
 
-  int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int tstep = gridDim.x;
-  TileXY cur = decomp(t), nxt = advance(cur);
-  if (t < a.ntiles) fetch(cur, 0);
   int buf = 0;
   bool first = true;
 #ifdef DSR_C64_STAMPS
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     asm volatile("" ::: "memory");
     STAMP(1);
     [[maybe_unused]] U4 rres[TR];
-    if constexpr (RES_EARLY) {
+    if (RES_EARLY && (MODE == 3 || (a.flags & DSR_F_RESIDUAL))) {
       // this tile's residual vectors (the two this thread will store over), requested BEFORE the next tile's DMA
       const int rn = cur.n, roy0 = cur.ty * TR, rox0 = cur.tx * 32;
       const bool rfull = roy0 + TR <= a.H && rox0 + 32 <= a.W;
@@ -323,18 +339,17 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     cur = nxt;
     nxt = advance(nxt);
     const bool full = oy0 + TR <= a.H && ox0 + 32 <= a.W;      // uniform: ragged tiles only at the bottom / right edge
-    // inference: eval-mode BatchNorm folded in.  The per-column scale / shift are fetched per tile (L1-resident) rather
-    // than held for the life of the block: the training path has no registers to spare
+    // inference: the per-channel scale / shift' pair of this lane's 2 x 4 channels, from LDS (never with PixelShuffle:
+    // channels 4g .. 4g + 3 of each n-tile are one 16-byte read)
     [[maybe_unused]] float sc_v[2][NB], sh_v[2][NB];
     if constexpr (FOLD) {
-      const bool aff = (a.flags & DSR_F_AFFINE) != 0;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < NB; ++r) {
-          sc_v[nt][r] = aff ? a.scale[c0 + chan(nt, r)] : 1.f;
-          sh_v[nt][r] = aff ? a.shift[c0 + chan(nt, r)] : 0.f;
-        }
+      for (int nt = 0; nt < 2; ++nt) {
+        const float4 sc4 = *reinterpret_cast<const float4*>(&sStat[0][0][wc * 32 + nt * 16 + 4 * g]);
+        const float4 sh4 = *reinterpret_cast<const float4*>(&sStat[0][1][wc * 32 + nt * 16 + 4 * g]);
+        sc_v[nt][0] = sc4.x, sc_v[nt][1] = sc4.y, sc_v[nt][2] = sc4.z, sc_v[nt][3] = sc4.w;
+        sh_v[nt][0] = sh4.x, sh_v[nt][1] = sh4.y, sh_v[nt][2] = sh4.z, sh_v[nt][3] = sh4.w;
+      }
     }
     // SM: 0 no statistics, 1 statistics of a full tile, 2 statistics of a ragged tile (out-of-image pixels masked)
     static_assert(32 * C_STRIDE == 4608, "immediates of the ds_write_b64 below");
@@ -449,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
           const int prow = (tid >> 3) + it * 32;
           if (!(oy0 + (prow >> 5) < a.H && ox0 + (prow & 31) < a.W)) off = OOB;
         }
-        if constexpr (RES_EARLY) {
+        if constexpr (MODE == 3) {
           if (a.flags & DSR_F_MASK) {           // (uniform) the prefetched tile is an activation output: y = conv * act'(o)
             v = act_mask8<DT>(v, rres[it], a.mask_act, a.mask_slope);
           } else {
@@ -464,8 +479,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
         if (FOLD && (a.flags & DSR_F_RESIDUAL)) {   // skip connection (generator.py:24,74): added after the activation
           float f[8], rr[8];
           unpack8<DT>(v, f);
-          unpack8<DT>(__builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(
-                          __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res), 0, a.y_bytes, 0x00020000), off, 0, 0)), rr);
+          unpack8<DT>(rres[it], rr);
 #pragma unroll
           for (int q = 0; q < 8; ++q) f[q] += rr[q];
           v = pack8<DT>(f);
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
 // tile rows per mode -- as many as the 256-register budget of two resident blocks allows WITHOUT a single spill (a spill is a
 // VMEM instruction: it would break the "exactly TR stores outstanding" count the tile loop waits on): plain 4, statistics 3
 // (the pixel-major epilogue needs more temporaries) and residual prefetch 3, folded inference epilogue 2
-static constexpr int c64_tile_rows(int mode) { return mode == 1 ? 4 : (mode == 2 ? 2 : 3); }
+static constexpr int c64_tile_rows(int mode) { return mode == 1 ? 4 : (mode == 2 ? 2 : 3); }   // (mode 2: 2 or 3, chosen per launch)
 static constexpr int c64_lds_bytes(int tr) { return 2 * (tr + 2) * 40 * 128 + tr * 32 * (64 * 2 + 16) + 2 * 2 * 64 * 4; }
 
 // spatial tiles of a launch whose tiles are `tr` rows x 32 columns
@@ -499,9 +513,8 @@ int dsr_c64_stat_rows(int N, int H, int W, int CoutP) {
   return ntiles < per_slice ? ntiles : per_slice;
 }
 
-template <int DT, int MODE>
+template <int DT, int MODE, int TR = c64_tile_rows(MODE)>
 static void c64_launch(const C64Args& a, dim3 grid, hipStream_t st) {
-  constexpr int TR = c64_tile_rows(MODE);
   constexpr int LDS = c64_lds_bytes(TR);
   auto* fn = conv_c64_kernel<DT, MODE, TR>;
   if constexpr (LDS > 64 * 1024) {
@@ -522,7 +535,17 @@ void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st) {
   const bool res_only = (a.flags & DSR_F_RESIDUAL) && !(a.flags & (DSR_F_AFFINE | DSR_F_PIXSHUF | DSR_F_STATS)) &&
                         a.act == DSR_ACT_NONE && slices == 1;
   const int mode = res_only ? 3 : (fold ? 2 : ((a.flags & DSR_F_STATS) ? 0 : 1));
-  const int tr = c64_tile_rows(mode);
+  int tr = c64_tile_rows(mode);
+  if (mode == 2) {
+    // inference images are often a few tiles per block only: take the tile height (2 or 3 rows) with the shorter longest
+    // block, counting a tile as its rows + 1 (halo rows and per-tile fixed work); 3 on a tie (fewer halo rows overall)
+    auto cost = [&](int r) {
+      const long long nt = (long long)N * ((a.H + r - 1) / r) * ((a.W + 31) / 32);
+      const long long per = 512 / slices;
+      return ((nt + per - 1) / per) * (r + 1);
+    };
+    tr = cost(3) <= cost(2) ? 3 : 2;
+  }
   a.tiles_y = (a.H + tr - 1) / tr;
   a.tiles_x = (a.W + 31) / 32;
   a.ntiles = N * a.tiles_y * a.tiles_x;
@@ -536,7 +559,8 @@ void dsr_launch_conv_c64(C64Args& a, int N, int dtype, hipStream_t st) {
 #define C64_LAUNCH(DTV)                              \
   do {                                               \
     if (mode == 3) c64_launch<DTV, 3>(a, grid, st);   \
-    else if (mode == 2) c64_launch<DTV, 2>(a, grid, st); \
+    else if (mode == 2 && tr == 3) c64_launch<DTV, 2, 3>(a, grid, st); \
+    else if (mode == 2) c64_launch<DTV, 2, 2>(a, grid, st); \
     else if (mode == 1) c64_launch<DTV, 1>(a, grid, st); \
     else c64_launch<DTV, 0>(a, grid, st);            \
   } while (0)
