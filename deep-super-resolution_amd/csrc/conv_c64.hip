@@ -77,6 +77,18 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   const bool do_stats = MODE == 0 && (a.flags & DSR_F_STATS) != 0;
   const bool pixshuf = (a.flags & DSR_F_PIXSHUF) != 0;
   const int wrow = (swp && pixshuf) ? 4 * (r16 & 3) + (r16 >> 2) : r16;
+  // ---- weights: registers, once (rows = output channels wc*32 + nt*16 + wrow).  Requested FIRST: they are the long pole of
+  // the prologue (36 x 16 B per lane, 2 us through the L1), and the integer set-up below runs under their latency (requested
+  // behind the first tile's DMA instead, every launch of a few tiles per block measured 2 us slower)
+  U4 fw[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        fw[t][kk][nt] = *reinterpret_cast<const U4*>(W + ((size_t)(t * a.CoutP + c0 + wc * 32 + nt * 16 + wrow)) * 64 + kk * 32 + g * 8);
+
   // A-fragment LDS offsets: halo column (16 wq + tx + r16) -> *128 + swizzled chunk (key = column & 7); + halo row * HC * 128
   int lds_off[3][2];
 #pragma unroll
@@ -171,22 +183,6 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     }
   };
 
-  int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int tstep = gridDim.x;
-  TileXY cur = decomp(t), nxt = advance(cur);
-  if (t < a.ntiles) fetch(cur, 0);
-  // ---- weights: registers, once (rows = output channels wc*32 + nt*16 + wrow).  Requested BEHIND the first tile's DMA, so
-  // that the two latencies overlap (a launch of a few tiles per block -- the x8 inference trunk, config 2 -- is mostly this prologue)
-  asm volatile("" ::: "memory");
-  U4 fw[9][2][2];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-        fw[t][kk][nt] = *reinterpret_cast<const U4*>(W + ((size_t)(t * a.CoutP + c0 + wc * 32 + nt * 16 + wrow)) * 64 + kk * 32 + g * 8);
-
   const float slope = (a.flags & DSR_F_PRELU_PTR) ? a.prelu[0] : a.slope;
   // channel of accumulator register r of n-tile nt: pixel-major layout: wc*32 + nt*16 + r16 (all r);
   // swapped: wc*32 + nt*16 + (4g + r), through the PixelShuffle row order: wc*32 + nt*16 + 4r + g
@@ -239,6 +235,10 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     st_step = 2 * (2 * a.W) * OCp * 2;                                 // conv row + 1 = output rows + 2
   }
 
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tstep = gridDim.x;
+  TileXY cur = decomp(t), nxt = advance(cur);
+  if (t < a.ntiles) fetch(cur, 0);
   int buf = 0;
   bool first = true;
 #ifdef DSR_C64_STAMPS
