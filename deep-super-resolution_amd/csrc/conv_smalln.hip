@@ -685,7 +685,7 @@ struct Tail9DgradArgs {
   void* dx;         // [N][H][W][64]
   int N, H, W;
   int strips, bands, rows_per_band;
-  unsigned dy_bytes;
+  unsigned dy_bytes, dx_bytes;
 };
 
 template <int DT>
@@ -767,9 +767,18 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_toeplitz9_kernel(const Tail
   const int px = 16 * wave + l16;                        // this lane's pixel (B' operand column) inside the strip
   const int b_off = px * 64 + ((g ^ ((px >> 2) & 3)) << 4);
   const int r_start = rb0 - 9;
+  // output rows leave by range-checked buffer stores: exactly two per thread and row, so that "at most two outstanding" at
+  // the top of the next row means the raw strip requested BEFORE them has landed (vmcnt retires in order) while the stores
+  // themselves stay in flight -- a vmcnt(0) there exposed the full store latency on every one of the block's rows
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(a.dx, 0, a.dx_bytes, 0x00020000);
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const unsigned sC_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)sC);
   dma_raw(r_start + 5);
   for (int r = r_start; r < rb1; ++r) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (also drains the previous row's output stores)
+    if (r > rb0)                                         // (uniform) the previous iteration stored a row
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (r + 1 < rb1) dma_raw(r + 6);
@@ -794,15 +803,21 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_toeplitz9_kernel(const Tail
         h.x = (unsigned)f2h<DT>(acc[mf][0]) | ((unsigned)f2h<DT>(acc[mf][1]) << 16);
         h.y = (unsigned)f2h<DT>(acc[mf][2]) | ((unsigned)f2h<DT>(acc[mf][3]) << 16);
         const int c16 = 2 * mf + (g >> 1);
-        *reinterpret_cast<uint2*>(sC + l16 * 128 + ((c16 ^ (l16 & 7)) << 4) + (g & 1) * 8) = h;
+        // inline asm: behind an in-flight LDS-DMA hipcc puts s_waitcnt vmcnt(0) in front of an 8-byte LDS store it can see
+        // (the raw strip requested at the top of this row would be waited for here, every row)
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        const u32x2 hv = {h.x, h.y};
+        asm volatile("ds_write_b64 %0, %1" ::"v"(sC_lds + (unsigned)(l16 * 128 + ((c16 ^ (l16 & 7)) << 4) + (g & 1) * 8)), "v"(hv) : "memory");
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the slab is this wave's own: no barrier)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int idx = lane + 64 * i;
         const int pp = idx >> 3, c16 = idx & 7;
         const U4 v = *reinterpret_cast<const U4*>(sC + pp * 128 + ((c16 ^ (pp & 7)) << 4));
         const int x = p0 + 16 * wave + pp;
-        if (x < W) *reinterpret_cast<U4*>(DX + (((size_t)n * H + r) * W + x) * 64 + c16 * 8) = v;
+        const unsigned off = (unsigned)((((n * H + r) * W + x) * 64 + c16 * 8) * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xrsrc, x < W ? off : OOB, 0, 0);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -824,6 +839,7 @@ void dsr_launch_dgrad_toeplitz(const void* dy, const void* w_dgrad, void* dx, in
   a.bands = t.tiles_y;
   a.rows_per_band = t.tiles_per_block;
   a.dy_bytes = (unsigned)((size_t)N * H * W * 16);
+  a.dx_bytes = (unsigned)((size_t)N * H * W * 128);      // (check_desc refuses tensors of 2 GiB or more)
   if (dtype == DSR_DTYPE_BF16)
     hipLaunchKernelGGL((conv_dgrad_toeplitz9_kernel<DSR_DTYPE_BF16>), dim3(t.ntiles), dim3(256), 0, st, a);
   else
