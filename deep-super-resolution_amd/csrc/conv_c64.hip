@@ -240,7 +240,11 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
   TileXY cur = decomp(t), nxt = advance(cur);
   if (t < a.ntiles) fetch(cur, 0);
   int buf = 0;
-  bool first = true;
+  // The weights and the first tile have to be there before the first MFMA anyway: wait HERE, with the builtin (an S_WAITCNT
+  // the compiler's wait-count pass sees, unlike inline asm).  Otherwise the pass has to cover the weight loads itself and, not
+  // knowing how many DMA pieces follow them, may put a vmcnt(0) in front of an MFMA INSIDE the tile loop -- where it also waits
+  // for the next tile's DMA, every tile (it did in the inference instantiation).  0x0F70 = vmcnt(0), expcnt / lgkmcnt untouched.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
 #ifdef DSR_C64_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -252,11 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     // The previous tile's TR output stores per thread (always issued: range-checked buffer stores) are younger than
     // this tile's DMA and stay in flight through the MFMA phase: vmcnt retires in order, so "at most 2 outstanding"
     // "at most TR outstanding" already means the DMA has landed.  A vmcnt(0) here exposed the full store latency per tile.
-    if (first)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TR) : "memory");
-    first = false;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TR) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     STAMP(1);
@@ -343,13 +343,21 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
     // channels 4g .. 4g + 3 of each n-tile are one 16-byte read)
     [[maybe_unused]] float sc_v[2][NB], sh_v[2][NB];
     if constexpr (FOLD) {
+      // (inline asm, the wait inside: an LDS read the compiler can see behind an in-flight LDS-DMA gets a vmcnt(0) in front
+      //  of it -- the next tile's halo would be waited for here, before the epilogue instead of under it)
+      typedef __attribute__((ext_vector_type(4))) float f4;
+      f4 q[4];
+      const unsigned a_sc = (unsigned)(size_t)((__attribute__((address_space(3))) float*)&sStat[0][0][wc * 32 + 4 * g]);
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:256\n\t"
+                   "ds_read_b128 %3, %4 offset:320\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]) : "v"(a_sc) : "memory");   // [1][c] is 64 floats behind [0][c]
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const float4 sc4 = *reinterpret_cast<const float4*>(&sStat[0][0][wc * 32 + nt * 16 + 4 * g]);
-        const float4 sh4 = *reinterpret_cast<const float4*>(&sStat[0][1][wc * 32 + nt * 16 + 4 * g]);
-        sc_v[nt][0] = sc4.x, sc_v[nt][1] = sc4.y, sc_v[nt][2] = sc4.z, sc_v[nt][3] = sc4.w;
-        sh_v[nt][0] = sh4.x, sh_v[nt][1] = sh4.y, sh_v[nt][2] = sh4.z, sh_v[nt][3] = sh4.w;
-      }
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sc_v[nt][r] = q[nt][r];
+          sh_v[nt][r] = q[2 + nt][r];
+        }
     }
     // SM: 0 no statistics, 1 statistics of a full tile, 2 statistics of a ragged tile (out-of-image pixels masked)
     static_assert(32 * C_STRIDE == 4608, "immediates of the ds_write_b64 below");
