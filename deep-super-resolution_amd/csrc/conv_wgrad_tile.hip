@@ -171,8 +171,8 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const WgradTileArgs& a, cons
   // ---- DMA loader: slot position (lane & 7) of pixel slot q = 32u + 8*wave + (lane >> 3) holds chunk (lane&7)^(q&7)
   const int chunk = (tid & 7) ^ ((tid >> 3) & 7), pb = tid >> 3;
   const bool yc_ok = (co0 + chunk * 8) < a.CoutP, xc_ok = (ci0 + chunk * 8) < a.CinP;
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
+  const BufSrd xrsrc = make_srd(const_cast<void*>(a.x), a.x_bytes);
+  const BufSrd yrsrc = make_srd(const_cast<void*>(a.dy), a.dy_bytes);
   constexpr unsigned OOB = 0xFFFFFFF0u;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int per_img = a.tiles_y * a.tiles_x;
@@ -206,34 +206,30 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const WgradTileArgs& a, cons
     const int oy0 = tc.ty * R, ox0 = tc.tx * 32;
     unsigned char* st = smem + buf * STAGE;
     if (fast) {
-      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x)) + (size_t)n * ximg, 0, ximg, 0x00020000);
-      const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.dy)) + (size_t)n * yimg, 0, yimg, 0x00020000);
+      const BufSrd xr = make_srd(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x)) + (size_t)n * ximg, ximg);
+      const BufSrd yr = make_srd(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.dy)) + (size_t)n * yimg, yimg);
       const int xs = ((oy0 - a.pad) * a.IW + ox0 - a.pad) * a.CinP * 2;       // negative above the image: out of range
       const int ys = (oy0 * a.OW + ox0) * a.CoutP * 2;
       unsigned char* dx = st + 8 * wave * 128;
       if (ox0 - a.pad >= 0 && ox0 - a.pad + 34 <= a.IW) {                        // interior columns
 #pragma unroll
         for (int u = 0; u < NX; ++u)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(dx + 32 * u * 128), 16, (unsigned)(xpart[u] + xs), 0, 0, 0);
+          lds_dma16(xr, dx + 32 * u * 128, (unsigned)(xpart[u] + xs));
       } else {
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
           const int ix = ox0 - a.pad + (int)((hc_pack >> (6 * u)) & 63);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(dx + 32 * u * 128), 16,
-                                                   (unsigned)ix < (unsigned)a.IW ? (unsigned)(xpart[u] + xs) : OOB, 0, 0, 0);
+          lds_dma16(xr, dx + 32 * u * 128, (unsigned)ix < (unsigned)a.IW ? (unsigned)(xpart[u] + xs) : OOB);
         }
       }
       if (ox0 + 32 <= a.OW) {
 #pragma unroll
         for (int u = 0; u < NY; ++u)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr)(dx + XB + 32 * u * 128), 16, (unsigned)(ypart[u] + ys), 0, 0, 0);
+          lds_dma16(yr, dx + XB + 32 * u * 128, (unsigned)(ypart[u] + ys));
       } else {
 #pragma unroll
         for (int u = 0; u < NY; ++u)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr)(dx + XB + 32 * u * 128), 16,
-                                                   ox0 + (pb & 31) < a.OW ? (unsigned)(ypart[u] + ys) : OOB, 0, 0, 0);
+          lds_dma16(yr, dx + XB + 32 * u * 128, ox0 + (pb & 31) < a.OW ? (unsigned)(ypart[u] + ys) : OOB);
       }
       return;
     }
@@ -244,18 +240,14 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const WgradTileArgs& a, cons
       bool ok = xc_ok && hc < 34;
       const int iy = pad_index(oy0 + hr - a.pad, a.IH, a.pad_mode, ok);
       const int ix = pad_index(ox0 + hc - a.pad, a.IW, a.pad_mode, ok);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(st + (32 * u + 8 * wave) * 128), 16,
-                                               ok ? (unsigned)((((n * a.IH + iy) * a.IW + ix) * a.CinP + ci0 + chunk * 8) * 2) : OOB,
-                                               0, 0, 0);
+      lds_dma16(xrsrc, st + (32 * u + 8 * wave) * 128, ok ? (unsigned)((((n * a.IH + iy) * a.IW + ix) * a.CinP + ci0 + chunk * 8) * 2) : OOB);
     }
 #pragma unroll
     for (int u = 0; u < (R * 32) / 32; ++u) {       // 2 per wave: the dY tile
       const int p = pb + 32 * u;
       const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
       const bool ok = yc_ok && oy < a.OH && ox < a.OW;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr)(st + XB + (32 * u + 8 * wave) * 128), 16,
-                                               ok ? (unsigned)((((n * a.OH + oy) * a.OW + ox) * a.CoutP + co0 + chunk * 8) * 2) : OOB,
-                                               0, 0, 0);
+      lds_dma16(yrsrc, st + XB + (32 * u + 8 * wave) * 128, ok ? (unsigned)((((n * a.OH + oy) * a.OW + ox) * a.CoutP + co0 + chunk * 8) * 2) : OOB);
     }
   };
   auto next_tile = [&](TileXY c) {                   // tiles of a block are consecutive
@@ -406,8 +398,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
   const int xchunk = (tid & 7) ^ ((4 * wave + (lane >> 4)) & 7);     // key of slot q = 32u + 8*wave + (lane>>3): (q>>1)&7
   const int ychunk = (tid & 7) ^ ((tid >> 3) & 7);
   const bool yc_ok = (co0 + ychunk * 8) < a.CoutP, xc_ok = (ci0 + xchunk * 8) < a.CinP;
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
+  const BufSrd xrsrc = make_srd(const_cast<void*>(a.x), a.x_bytes);
+  const BufSrd yrsrc = make_srd(const_cast<void*>(a.dy), a.dy_bytes);
   constexpr unsigned OOB = 0xFFFFFFF0u;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int per_img = a.tiles_y * a.tiles_x;
@@ -434,10 +426,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
     const int n = tc.n, oy0 = tc.ty, ox0 = tc.tx * 32;
     unsigned char* st = smem + buf * STAGE;
     if (fast) {
-      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x)) + (size_t)n * ximg, 0, ximg, 0x00020000);
-      const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.dy)) + (size_t)n * yimg, 0, yimg, 0x00020000);
+      const BufSrd xr = make_srd(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x)) + (size_t)n * ximg, ximg);
+      const BufSrd yr = make_srd(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.dy)) + (size_t)n * yimg, yimg);
       const int ix0 = ox0 * 2 - a.pad;
       const int xs = ((oy0 * 2 - a.pad) * a.IW + ix0) * a.CinP * 2;
       const int ys = (oy0 * a.OW + ox0) * a.CoutP * 2;
@@ -451,11 +441,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
             const int hc = (int)(((u < 4 ? hc_lo >> (7 * u) : hc_hi >> (7 * (u - 4)))) & 127);
             if (!((unsigned)(ix0 + hc) < (unsigned)a.IW)) off = OOB;
           }
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(dx + 32 * u * 128), 16, off, 0, 0, 0);
+          lds_dma16(xr, dx + 32 * u * 128, off);
         }
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr)(dx + XB), 16,
-                                               (ox0 + 32 <= a.OW || ox0 + pb < a.OW) ? (unsigned)(ypart + ys) : OOB, 0, 0, 0);
+      lds_dma16(yr, dx + XB, (ox0 + 32 <= a.OW || ox0 + pb < a.OW) ? (unsigned)(ypart + ys) : OOB);
       return;
     }
 #pragma unroll
@@ -466,17 +455,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
         bool ok = xc_ok && hc < 65;
         const int iy = pad_index(oy0 * 2 + hr - a.pad, a.IH, a.pad_mode, ok);
         const int ix = pad_index(ox0 * 2 + hc - a.pad, a.IW, a.pad_mode, ok);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(st + (32 * u + 8 * wave) * 128), 16,
-                                                 ok ? (unsigned)((((n * a.IH + iy) * a.IW + ix) * a.CinP + ci0 + xchunk * 8) * 2) : OOB,
-                                                 0, 0, 0);
+        lds_dma16(xrsrc, st + (32 * u + 8 * wave) * 128, ok ? (unsigned)((((n * a.IH + iy) * a.IW + ix) * a.CinP + ci0 + xchunk * 8) * 2) : OOB);
       }
     }
     {
       const int ox = ox0 + pb;
       const bool ok = yc_ok && ox < a.OW;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr)(st + XB + 8 * wave * 128), 16,
-                                               ok ? (unsigned)((((n * a.OH + oy0) * a.OW + ox) * a.CoutP + co0 + ychunk * 8) * 2) : OOB,
-                                               0, 0, 0);
+      lds_dma16(yrsrc, st + XB + 8 * wave * 128, ok ? (unsigned)((((n * a.OH + oy0) * a.OW + ox) * a.CoutP + co0 + ychunk * 8) * 2) : OOB);
     }
   };
 

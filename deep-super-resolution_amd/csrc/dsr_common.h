@@ -188,6 +188,30 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
   p -= c.step_size * (m / (sqrtf(v) * c.rbc2 + c.eps));
 }
 
+// LDS-DMA (buffer_load_dwordx4 ... lds: 64 lanes x 16 B, lane-linear from the LDS address in M0) issued by INLINE ASM.
+// hipcc's wait-count pass tracks the builtin form (__builtin_amdgcn_raw_ptr_buffer_load_lds) as a pending LDS write and puts
+// s_waitcnt vmcnt(0) in front of every LDS access it cannot prove disjoint from it -- 8-byte LDS stores and every transposing
+// read (ds_read_b64_tr_b16): a prefetch issued before a tile's MFMA phase is then waited for at that phase's FIRST operand
+// read, and the two never overlap.  Issued by asm the DMA is invisible to the pass; the kernel waits itself (s_waitcnt
+// vmcnt(N) + barrier) where the tile is needed.  Compiler-generated vmcnt waits stay correct: vmcnt retires in order, so
+// operations the pass does not know about only ever make one of its waits stricter.
+typedef __attribute__((ext_vector_type(4))) unsigned dsr_u32x4;
+struct BufSrd {
+  dsr_u32x4 w;   // raw buffer resource: base[47:0], stride 0, num_records = bytes, flags as __builtin_amdgcn_make_buffer_rsrc(.., 0x00020000)
+};
+__device__ __forceinline__ BufSrd make_srd(const void* base, unsigned bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  BufSrd r;
+  r.w = dsr_u32x4{(unsigned)b, (unsigned)(b >> 32) & 0xffffu, bytes, 0x00020000u};
+  return r;
+}
+// `lds`: wave-uniform pointer into shared memory (this wave's 1 KB slot row); `voff`: per-lane byte offset into the buffer
+// (an out-of-range offset writes zeros)
+__device__ __forceinline__ void lds_dma16(const BufSrd& srd, const void* lds, unsigned voff) {
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) const void*)lds));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(l), "v"(voff), "s"(srd.w) : "memory");
+}
+
 // XCD-aware, bijective block-id remap (consecutive logical tiles share an XCD's L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int nx = 8;
