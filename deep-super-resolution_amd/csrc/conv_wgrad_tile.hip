@@ -140,33 +140,33 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const WgradTileArgs& a, cons
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it (and what derives from it) in SGPRs
-  const int wr = wave >> 1, wc = wave & 1;
+  // A wave owns all 64 output channels (4 m-tiles) of a 16-input-channel strip (one n-tile): an X fragment -- the operand that
+  // changes with every tap column and halo row -- then feeds 4 MFMAs per output row instead of 2, and a tile costs a wave
+  // 8 dY + 12 X fragment reads for its 72 MFMAs instead of 4 + 24 (the 2 x 2 wave grid of 32 x 32 quadrants): the kernel is
+  // bound by the LDS port (taking the DMA wait out altogether changed nothing), so reads per MFMA are what counts.  Every
+  // accumulator still sums the same products in the same order: bit-identical.
   const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
   const int co0 = (pair / a.tiles_ci) * 64, ci0 = (pair % a.tiles_ci) * 64;
 
-  f32x4 acc[9][2][2];
+  f32x4 acc[9][4];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- fragment read offsets (bytes inside a stage): rows lp = 4g + q4 (and lp + 16 at +2048)
   const int lp = 4 * g + q4;
-  int offA[2], offB[3][2];
+  int offA[4], offB[3];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ch = wr * 32 + i * 16 + cc;
+  for (int i = 0; i < 4; ++i) {
+    const int ch = i * 16 + cc;
     offA[i] = XB + lp * 128 + (((ch >> 3) ^ (lp & 7)) << 4) + (ch & 7) * 2;
   }
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int ch = wc * 32 + j * 16 + cc;
-      offB[kw][j] = lp * 128 + (((ch >> 3) ^ ((kw + lp) & 7)) << 4) + (ch & 7) * 2;
-    }
+  for (int kw = 0; kw < 3; ++kw) {
+    const int ch = wave * 16 + cc;
+    offB[kw] = lp * 128 + (((ch >> 3) ^ ((kw + lp) & 7)) << 4) + (ch & 7) * 2;
+  }
 
   // ---- DMA loader: slot position (lane & 7) of pixel slot q = 32u + 8*wave + (lane >> 3) holds chunk (lane&7)^(q&7)
   const int chunk = (tid & 7) ^ ((tid >> 3) & 7), pb = tid >> 3;
@@ -288,22 +288,22 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const WgradTileArgs& a, cons
       return __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     constexpr int NU = 3 * HR;                         // units u = kw * HR + h
-    auto load_b = [&](int u, U4* dst) {
+    auto load_b = [&](int u) {
       const int kw = u / HR, h = u - kw * HR;
-      dst[0] = frag(offB[kw][0] + (h * HC + kw) * 128);
-      dst[1] = frag(offB[kw][1] + (h * HC + kw) * 128);
+      return frag(offB[kw] + (h * HC + kw) * 128);
     };
-    U4 fa[R][2], fb[3][2];
+    U4 fa[R][4], fb[3];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      fa[r][0] = frag(offA[0] + r * 32 * 128);
-      fa[r][1] = frag(offA[1] + r * 32 * 128);
-    }
-    load_b(0, fb[0]);
-    load_b(1, fb[1]);
+    for (int i = 0; i < 4; ++i) fa[0][i] = frag(offA[i]);
+    fb[0] = load_b(0);
+    fb[1] = load_b(1);
+#pragma unroll
+    for (int r = 1; r < R; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[r][i] = frag(offA[i] + r * 32 * 128);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      if (u + 2 < NU) load_b(u + 2, fb[(u + 2) % 3]);
+      if (u + 2 < NU) fb[(u + 2) % 3] = load_b(u + 2);
       __builtin_amdgcn_sched_barrier(0);
       const int kw = u / HR, h = u - kw * HR;
 #pragma unroll
@@ -311,9 +311,7 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const WgradTileArgs& a, cons
         const int kh = h - r;
         if (kh < 0 || kh > 2) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[kh * 3 + kw][i][j] = mfma16<DT>(fa[r][i], fb[u % 3][j], acc[kh * 3 + kw][i][j]);
+        for (int i = 0; i < 4; ++i) acc[kh * 3 + kw][i] = mfma16<DT>(fa[r][i], fb[u % 3], acc[kh * 3 + kw][i]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -323,14 +321,12 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const WgradTileArgs& a, cons
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = co0 + wr * 32 + i * 16 + 4 * g + r, ci = ci0 + wc * 32 + j * 16 + l16;
-          if (co < a.CoutP && ci < a.CinP) P[((size_t)tp * a.CoutP + co) * a.CinP + ci] = acc[tp][i][j][r];
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + i * 16 + 4 * g + r, ci = ci0 + wave * 16 + l16;
+        if (co < a.CoutP && ci < a.CinP) P[((size_t)tp * a.CoutP + co) * a.CinP + ci] = acc[tp][i][r];
+      }
 }
 
 template <int DT>
