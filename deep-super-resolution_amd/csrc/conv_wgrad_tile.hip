@@ -362,33 +362,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it (and what derives from it) in SGPRs
-  const int wr = wave >> 1, wc = wave & 1;
+  // (a wave owns all 64 output channels of a 16-input-channel strip, as in conv_wgrad_dma_body: 4 + 9 fragment reads per
+  //  tile instead of 2 + 18)
   const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
   const int pair = blockIdx.x;
   const int co0 = (pair / a.tiles_ci) * 64, ci0 = (pair % a.tiles_ci) * 64;
 
-  f32x4 acc[9][2][2];
+  f32x4 acc[9][4];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int lp = 4 * g + q4;
-  int offA[2], offB[2][2];                 // offB[kw >> 1][j]
+  int offA[4], offB[2];                    // offB[kw >> 1]
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ch = wr * 32 + i * 16 + cc;
+  for (int i = 0; i < 4; ++i) {
+    const int ch = i * 16 + cc;
     offA[i] = XB + lp * 128 + (((ch >> 3) ^ (lp & 7)) << 4) + (ch & 7) * 2;
   }
 #pragma unroll
-  for (int v = 0; v < 2; ++v)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int ch = wc * 32 + j * 16 + cc;
-      offB[v][j] = 2 * lp * 128 + (((ch >> 3) ^ ((lp + v) & 7)) << 4) + (ch & 7) * 2;
-    }
+  for (int v = 0; v < 2; ++v) {
+    const int ch = wave * 16 + cc;
+    offB[v] = 2 * lp * 128 + (((ch >> 3) ^ ((lp + v) & 7)) << 4) + (ch & 7) * 2;
+  }
 
   const int pb = tid >> 3;
   const int xchunk = (tid & 7) ^ ((4 * wave + (lane >> 4)) & 7);     // key of slot q = 32u + 8*wave + (lane>>3): (q>>1)&7
@@ -484,32 +481,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
     if (t + 1 < t_end) dma(nxt, buf ^ 1);
     const unsigned char* st = smem + buf * STAGE;
     // the 9 taps as a software pipeline (see conv_wgrad_dma_body): X fragments of tap u + 2 requested before the MFMAs of tap u
-    U4 fa[2], fb[3][2];
-    auto load_b = [&](int u, U4* dst) {
+    U4 fa[4], fb[3];
+    auto load_b = [&](int u) {
       const int kh = u / 3, kw = u % 3;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const s16x4 lo = tr_read(st + offB[kw >> 1][j] + (kh * HC + kw) * 128);
-        const s16x4 hi = tr_read(st + offB[kw >> 1][j] + (kh * HC + kw) * 128 + 32 * 128);
-        dst[j] = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-      }
+      const s16x4 lo = tr_read(st + offB[kw >> 1] + (kh * HC + kw) * 128);
+      const s16x4 hi = tr_read(st + offB[kw >> 1] + (kh * HC + kw) * 128 + 32 * 128);
+      return __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
       const s16x4 lo = tr_read(st + offA[i]);
       const s16x4 hi = tr_read(st + offA[i] + 2048);
       fa[i] = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
-    load_b(0, fb[0]);
-    load_b(1, fb[1]);
+    fb[0] = load_b(0);
+    fb[1] = load_b(1);
 #pragma unroll
     for (int u = 0; u < 9; ++u) {
-      if (u + 2 < 9) load_b(u + 2, fb[(u + 2) % 3]);
+      if (u + 2 < 9) fb[(u + 2) % 3] = load_b(u + 2);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[u][i][j] = mfma16<DT>(fa[i], fb[u % 3][j], acc[u][i][j]);
+      for (int i = 0; i < 4; ++i) acc[u][i] = mfma16<DT>(fa[i], fb[u % 3], acc[u][i]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -518,14 +510,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = co0 + wr * 32 + i * 16 + 4 * g + r, ci = ci0 + wc * 32 + j * 16 + l16;
-          if (co < a.CoutP && ci < a.CinP) P[((size_t)tp * a.CoutP + co) * a.CinP + ci] = acc[tp][i][j][r];
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + i * 16 + 4 * g + r, ci = ci0 + wave * 16 + l16;
+        if (co < a.CoutP && ci < a.CinP) P[((size_t)tp * a.CoutP + co) * a.CinP + ci] = acc[tp][i][r];
+      }
 }
 
 int dsr_wgrad_tile_plan(int KH, int KW, int stride, int N, int OH, int OW, int CinP, int CoutP, WgradTileArgs* a) {
