@@ -268,6 +268,7 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const WgradTileArgs& a, cons
   nxt.n = t / per_img;
   nxt.ty = (t - nxt.n * per_img) / a.tiles_x;
   nxt.tx = t - nxt.n * per_img - nxt.ty * a.tiles_x;
+  __builtin_amdgcn_s_setprio(1);
   if (t < t_end) dma(nxt, 0);
   int buf = 0;
   for (; t < t_end; ++t, buf ^= 1) {
@@ -276,6 +277,11 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const WgradTileArgs& a, cons
     asm volatile("" ::: "memory");
     nxt = next_tile(nxt);
     if (t + 1 < t_end) dma(nxt, buf ^ 1);
+    // The co-resident wave of the other block on this SIMD is, most of the time, in its MFMA phase.  Vector issue is arbitrated
+    // by priority, then age: at equal priority the ~50 instructions of a fetch (7 LDS-DMA requests among them) got a slot
+    // now and then between the partner's MFMAs -- s_memtime stamps: a third of a tile's time.  They run at priority 1 (set at
+    // the end of the MFMA phase below); the MFMA stream fills the slots that leaves (conv_c64.hip).
+    __builtin_amdgcn_s_setprio(0);
     const unsigned char* st = smem + buf * STAGE;
     // An X fragment (16 pixels of halo row h at tap column kw) serves BOTH tile rows: row r = h - kh for the tap rows kh that
     // keep r inside the tile -- 12 fragment pairs per tile instead of 18 (row, tap) pairs, a third fewer LDS reads per MFMA.
@@ -315,6 +321,7 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const WgradTileArgs& a, cons
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_s_setprio(1);
   }
 
   float* P = a.partial + (size_t)ychunk * 9 * a.CoutP * a.CinP;
@@ -465,6 +472,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
   nxt.n = t / per_img;
   nxt.ty = (t - nxt.n * per_img) / a.tiles_x;
   nxt.tx = t - nxt.n * per_img - nxt.ty * a.tiles_x;
+  __builtin_amdgcn_s_setprio(1);
   if (t < t_end) dma(nxt, 0);
   int buf = 0;
   for (; t < t_end; ++t, buf ^= 1) {
@@ -479,6 +487,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
       }
     }
     if (t + 1 < t_end) dma(nxt, buf ^ 1);
+    __builtin_amdgcn_s_setprio(0);                   // (fetch at priority 1, MFMA phase at 0: see conv_wgrad_dma_body)
     const unsigned char* st = smem + buf * STAGE;
     // the 9 taps as a software pipeline (see conv_wgrad_dma_body): X fragments of tap u + 2 requested before the MFMAs of tap u
     U4 fa[4], fb[3];
@@ -504,6 +513,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
       for (int i = 0; i < 4; ++i) acc[u][i] = mfma16<DT>(fa[i], fb[u % 3], acc[u][i]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_s_setprio(1);
   }
 
   float* P = a.partial + (size_t)blockIdx.y * 9 * a.CoutP * a.CinP;
