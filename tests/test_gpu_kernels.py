@@ -86,6 +86,9 @@ CONV_CASES = [
     ("d_512", 1, 256, 512, 6, 6, 3, 1, 1, 0, "none"),
     ("dip_reflect_s2", 1, 32, 128, 16, 16, 3, 2, 1, 1, "none"),
     ("dip_reflect_132", 1, 132, 128, 10, 12, 3, 1, 1, 1, "none"),
+    ("dip_reflect_128", 2, 128, 128, 13, 19, 3, 1, 1, 1, "leaky"),      # reflect padding on the LDS-DMA path (padded coordinates per K-step)
+    ("dip_reflect_128_s2", 1, 128, 128, 16, 18, 3, 2, 1, 1, "none"),
+    ("dip_reflect_256_192", 1, 256, 192, 9, 11, 3, 1, 1, 1, "none"),
     ("dip_1x1_skip", 1, 32, 4, 12, 12, 1, 1, 0, 1, "none"),
     ("dip_1x1_128", 2, 128, 128, 8, 8, 1, 1, 0, 0, "leaky"),
     ("cout3_9x9", 1, 64, 3, 12, 12, 9, 1, 4, 0, "none"),
@@ -466,6 +469,50 @@ def test_first_layer_fused_backward(dev, n, h, w, actn):
     assert rel_err(dw_f, wr.grad) < 2.5e-2 and rel_err(db_f, br.grad) < 2.5e-2
     # fused vs unfused: the fused kernel multiplies in fp32 and rounds g once, the unfused path stores g in bf16 first
     assert rel_err(dw_f, dw_u) < 5e-3 and rel_err(db_f, db_u) < 5e-3
+
+
+@pytest.mark.parametrize("pmode,stride", [(1, 1), (1, 2), (2, 1)])
+def test_padded_coordinate_dma_path_equals_generic_loader(dev, pmode, stride):
+    """Reflect (1) / replicate (2) padding with Cin % 64 == 0 runs on the LDS-DMA kernel, which recomputes the padded
+    coordinate of every tile row per K-step; DSR_CONV_PADX=0 sends the same launch through the register-staged generic loader.
+    Same K order, same tile: the two must agree BIT FOR BIT (models/DIP/utils.py:83-105, pad='reflection')."""
+    import ctypes as C
+    import os
+    L = P("_lib")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n, h, w, cin, cout = 2, 21, 30, 128, 160
+    d = L.ConvDesc(L.F16, n, h, w, cin, cout, 3, 3, stride, 1, pmode)
+    oh, ow = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    g = torch.Generator(device="cpu").manual_seed(11)
+    wt = ((torch.rand(cout, cin, 3, 3, generator=g) - 0.5) * 0.1).to(dev)
+    wf = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 0), dtype=torch.float16, device=dev)
+    wd = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 1), dtype=torch.float16, device=dev)
+    L.check(lib.dsr_conv_pack_weight(C.byref(d), wt.data_ptr(), wf.data_ptr(), wd.data_ptr(), st))
+    x = (torch.rand(n, h, w, cin, generator=g) - 0.5).to(torch.float16).to(dev)
+    bias = (torch.rand(cout, generator=g) - 0.5).to(dev)
+    outs = []
+    old = os.environ.get("DSR_CONV_PADX")
+    try:
+        for mode in ("0", "1"):
+            os.environ["DSR_CONV_PADX"] = mode
+            y = torch.full((n, oh, ow, cout), float("nan"), dtype=torch.float16, device=dev)
+            ep = L.Epilogue(1, 0.2, None, bias.data_ptr(), None, 0, None, None, None, None)
+            L.check(lib.dsr_conv_fwd(C.byref(d), x.data_ptr(), wf.data_ptr(), C.byref(ep), y.data_ptr(), st))
+            torch.cuda.synchronize()
+            outs.append(y)
+    finally:
+        if old is None:
+            os.environ.pop("DSR_CONV_PADX", None)
+        else:
+            os.environ["DSR_CONV_PADX"] = old
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
+    # and against torch on the padded image
+    xp = TF.pad(x.float().permute(0, 3, 1, 2).cpu(), (1, 1, 1, 1), mode="reflect" if pmode == 1 else "replicate")
+    ref = TF.leaky_relu(TF.conv2d(xp, wt.half().float().cpu(), bias.cpu(), stride=stride), 0.2)
+    got = outs[1].float().permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("op", ["fwd", "fwd_stats", "dgrad", "dgrad_s2"])

@@ -663,8 +663,11 @@ def test_dip_step_vs_oracle(dev):
         loss, out = run.step(noise.to(dev))
         rloss, rout = recipes.dip_step(st, lr_img, noise)
         with lowp.storage(torch.float16):
-            _, sout = recipes.dip_step(sim, lr_img, noise)
-        assert abs(loss.item() - rloss) < 0.03 * abs(rloss), (it, loss.item(), rloss)
+            sloss, sout = recipes.dip_step(sim, lr_img, noise)
+        # floor-relative, like the outputs below: the fp16-storage oracle itself is 0.6 % / 2 % off the fp32 one after two /
+        # three steps of this chaotic trajectory (lr 0.01), and a last-bit change of the target image moves the HIP loss of the
+        # third step by 2 %
+        assert abs(loss.item() - rloss) < max(0.03 * abs(rloss), 3.0 * abs(float(sloss) - float(rloss))), (it, loss.item(), rloss, float(sloss))
         floor = (sout - rout).abs().max().item()
         assert (out.cpu() - rout).abs().max().item() <= 3.0 * floor + 0.01, (it, floor)
 
