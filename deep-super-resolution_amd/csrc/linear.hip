@@ -99,6 +99,106 @@ __global__ __launch_bounds__(256) void flatten_kernel(const unsigned short* __re
   }
 }
 
+// The same three copies through LDS for the shapes the dense head has (Cp a multiple of 64; HW, resp. Bp, a multiple of 8): a
+// block moves one 64-item x 64-channel tile, 16 bytes per lane and full 128-byte lines on BOTH sides (the strided form above
+// fetched every source line 4-5 times: 319 MB of reads per 67 MB tensor in the PMC pass).  mode 0 / 1: [item][channel] ->
+// [channel][item] with item = pixel / batch sample; mode 2 the inverse.  Rows of 65 halfwords + 1: the 2-byte column walks of
+// the transposing side fall on distinct banks.
+template <int DT>
+__global__ __launch_bounds__(256) void flatten_tile_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
+                                                           int B, int HW, int C, int Cp, int Bp, int mode) {
+  constexpr int PITCH = 66;                                  // halfwords per LDS row (64 + 2: keeps 4-byte alignment of the rows)
+  __shared__ unsigned short tile[64 * PITCH];
+  const int tid = threadIdx.x;
+  const int cgroups = Cp / 64;
+  const int cg = blockIdx.x % cgroups;
+  const int c0 = cg * 64;
+  const size_t K = (size_t)C * HW;
+  if (mode == 0 || mode == 2) {
+    const int ptiles = (HW + 63) / 64;
+    const int pt = (blockIdx.x / cgroups) % ptiles, b = blockIdx.x / (cgroups * ptiles);
+    const int p0 = pt * 64;
+    if (mode == 0) {
+      // in: act[b][p0 + r][c0 + 8j ..]  ->  tile[r][8j ..]
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = (tid >> 3) + 32 * i, j = tid & 7;
+        U4 v = U4{0u, 0u, 0u, 0u};
+        if (p0 + r < HW) v = *reinterpret_cast<const U4*>(src + ((size_t)b * HW + p0 + r) * Cp + c0 + 8 * j);
+        unsigned* t32 = reinterpret_cast<unsigned*>(tile + r * PITCH + 8 * j);
+        t32[0] = v.x, t32[1] = v.y, t32[2] = v.z, t32[3] = v.w;
+      }
+      __syncthreads();
+      // out: flat[b][(c0 + c) * HW + p0 + 8v ..] = tile[8v + k][c], k = 0..7
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = (tid >> 3) + 32 * i, v8 = tid & 7;
+        if (c0 + c < C && p0 + 8 * v8 < HW) {                // (HW % 8 == 0: a vector is inside or outside as a whole)
+          unsigned short e[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) e[k] = tile[(8 * v8 + k) * PITCH + c];
+          U4 o;
+          o.x = e[0] | ((unsigned)e[1] << 16), o.y = e[2] | ((unsigned)e[3] << 16);
+          o.z = e[4] | ((unsigned)e[5] << 16), o.w = e[6] | ((unsigned)e[7] << 16);
+          *reinterpret_cast<U4*>(dst + (size_t)b * K + (size_t)(c0 + c) * HW + p0 + 8 * v8) = o;
+        }
+      }
+    } else {
+      // in: flat[b][(c0 + c) * HW + p0 + 8v ..]  ->  tile[c][8v ..]     (pad channels: zeros)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = (tid >> 3) + 32 * i, v8 = tid & 7;
+        U4 v = U4{0u, 0u, 0u, 0u};
+        if (c0 + c < C && p0 + 8 * v8 < HW) v = *reinterpret_cast<const U4*>(src + (size_t)b * K + (size_t)(c0 + c) * HW + p0 + 8 * v8);
+        unsigned* t32 = reinterpret_cast<unsigned*>(tile + c * PITCH + 8 * v8);
+        t32[0] = v.x, t32[1] = v.y, t32[2] = v.z, t32[3] = v.w;
+      }
+      __syncthreads();
+      // out: act[b][p0 + r][c0 + 8j ..] = tile[8j + k][r]
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = (tid >> 3) + 32 * i, j = tid & 7;
+        if (p0 + r < HW) {
+          unsigned short e[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) e[k] = tile[(8 * j + k) * PITCH + r];
+          U4 o;
+          o.x = e[0] | ((unsigned)e[1] << 16), o.y = e[2] | ((unsigned)e[3] << 16);
+          o.z = e[4] | ((unsigned)e[5] << 16), o.w = e[6] | ((unsigned)e[7] << 16);
+          *reinterpret_cast<U4*>(dst + ((size_t)b * HW + p0 + r) * Cp + c0 + 8 * j) = o;
+        }
+      }
+    }
+  } else {
+    // mode 1: flatT[(c0 + c) * HW + p][b0 + 8v ..] = act[b0 + 8v + k][p][c0 + c]   (b >= B: zeros)
+    const int btiles = (Bp + 63) / 64;
+    const int bt = (blockIdx.x / cgroups) % btiles, p = blockIdx.x / (cgroups * btiles);
+    const int b0 = bt * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (tid >> 3) + 32 * i, j = tid & 7;
+      U4 v = U4{0u, 0u, 0u, 0u};
+      if (b0 + r < B) v = *reinterpret_cast<const U4*>(src + ((size_t)(b0 + r) * HW + p) * Cp + c0 + 8 * j);
+      unsigned* t32 = reinterpret_cast<unsigned*>(tile + r * PITCH + 8 * j);
+      t32[0] = v.x, t32[1] = v.y, t32[2] = v.z, t32[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = (tid >> 3) + 32 * i, v8 = tid & 7;
+      if (c0 + c < C && b0 + 8 * v8 < Bp) {                  // (Bp % 8 == 0)
+        unsigned short e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = tile[(8 * v8 + k) * PITCH + c];
+        U4 o;
+        o.x = e[0] | ((unsigned)e[1] << 16), o.y = e[2] | ((unsigned)e[3] << 16);
+        o.z = e[4] | ((unsigned)e[5] << 16), o.w = e[6] | ((unsigned)e[7] << 16);
+        *reinterpret_cast<U4*>(dst + ((size_t)(c0 + c) * HW + p) * Bp + b0 + 8 * v8) = o;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ forward: split-K partials
 // W is [O][K] row-major and the reduction runs along the contiguous axis, so an MFMA operand read straight from
 // global memory puts adjacent lanes on rows 2K bytes apart (64 separate cache lines per load instruction: measured
@@ -566,6 +666,20 @@ extern "C" int dsr_flatten(int dtype, const void* src, void* dst, int B, int HW,
   DSR_REQUIRE(src && dst && DSR_DTYPE_OK(dtype) && B > 0 && HW > 0 && C > 0 && Cp >= C && mode >= 0 && mode <= 2 && (mode != 1 || Bp >= B), "flatten: null pointer or bad shape");
   if (Cp % 8) return dsr_fail(DSR_E_ARG, "flatten: Cp %% 8 != 0");
   const size_t cgroups = (size_t)(Cp + 63) / 64;
+  // DSR_FLATTEN_TILE (tuning switch, read per call: a test compares the two forms): 0 = the strided form for every shape
+  const char* ft = getenv("DSR_FLATTEN_TILE");
+  if (!(ft && ft[0] == '0') && Cp % 64 == 0 && (mode == 1 ? Bp % 8 == 0 : HW % 8 == 0)) {
+    const size_t tiles = (mode == 1 ? (size_t)HW * ((Bp + 63) / 64) : (size_t)B * ((HW + 63) / 64)) * cgroups;
+    if (tiles < (1ull << 31)) {
+      if (dtype == DSR_BF16)
+        hipLaunchKernelGGL((flatten_tile_kernel<DSR_DTYPE_BF16>), dim3((unsigned)tiles), dim3(256), 0, st, (const unsigned short*)src,
+                           (unsigned short*)dst, B, HW, C, Cp, Bp, mode);
+      else
+        hipLaunchKernelGGL((flatten_tile_kernel<DSR_DTYPE_F16>), dim3((unsigned)tiles), dim3(256), 0, st, (const unsigned short*)src,
+                           (unsigned short*)dst, B, HW, C, Cp, Bp, mode);
+      return dsr_launch_status("dsr_flatten");
+    }
+  }
   const size_t waves = mode == 1 ? (size_t)HW * ((Bp + 63) / 64) * cgroups : (size_t)B * ((HW + 63) / 64) * cgroups;
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   if (dtype == DSR_BF16)

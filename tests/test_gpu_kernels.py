@@ -471,6 +471,50 @@ def test_first_layer_fused_backward(dev, n, h, w, actn):
     assert rel_err(dw_f, dw_u) < 5e-3 and rel_err(db_f, db_u) < 5e-3
 
 
+@pytest.mark.parametrize("b,hw,c,cp,bp", [(5, 72, 100, 128, 8), (64, 1024, 512, 512, 64), (3, 8, 64, 64, 16)])
+def test_flatten_tile_kernel_equals_strided_form(dev, b, hw, c, cp, bp):
+    """dsr_flatten (NHWC <-> the CHW-flattened operand of the dense head, discriminator.py:37-39,60-62) has a tile form that
+    goes through LDS with 16-byte accesses on both sides; DSR_FLATTEN_TILE=0 keeps the strided form.  Pure data movement:
+    the two must agree bit for bit in all three modes, and with torch's permute."""
+    import ctypes as C
+    import os
+    L = P("_lib")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    act = (torch.rand(b, hw, cp, generator=g) - 0.5).to(torch.bfloat16)
+    act[..., c:] = 0
+    act = act.to(dev)
+    flat_src = (torch.rand(b, c * hw, generator=g) - 0.5).to(torch.bfloat16).to(dev)
+    res = {}
+    old = os.environ.get("DSR_FLATTEN_TILE")
+    try:
+        for tag in ("1", "0"):
+            os.environ["DSR_FLATTEN_TILE"] = tag
+            flat = torch.full((b, c * hw), float("nan"), dtype=torch.bfloat16, device=dev)
+            L.check(lib.dsr_flatten(L.BF16, act.data_ptr(), flat.data_ptr(), b, hw, c, cp, 0, 0, st))
+            flat_t = torch.full((c * hw, bp), float("nan"), dtype=torch.bfloat16, device=dev)
+            L.check(lib.dsr_flatten(L.BF16, act.data_ptr(), flat_t.data_ptr(), b, hw, c, cp, bp, 1, st))
+            back = torch.full((b, hw, cp), float("nan"), dtype=torch.bfloat16, device=dev)
+            L.check(lib.dsr_flatten(L.BF16, flat_src.data_ptr(), back.data_ptr(), b, hw, c, cp, 0, 2, st))
+            torch.cuda.synchronize()
+            res[tag] = (flat, flat_t, back)
+    finally:
+        if old is None:
+            os.environ.pop("DSR_FLATTEN_TILE", None)
+        else:
+            os.environ["DSR_FLATTEN_TILE"] = old
+    for u, v in zip(res["1"], res["0"]):
+        assert torch.isfinite(u.float()).all()
+        assert torch.equal(u, v)
+    flat, flat_t, back = res["1"]
+    ref = act[..., :c].permute(0, 2, 1).reshape(b, c * hw)
+    assert torch.equal(flat, ref)
+    assert torch.equal(flat_t[:, :b], ref.t()) and float(flat_t[:, b:].float().abs().max() if bp > b else 0.0) == 0.0
+    refb = flat_src.reshape(b, c, hw).permute(0, 2, 1)
+    assert torch.equal(back[..., :c], refb) and float(back[..., c:].float().abs().max() if cp > c else 0.0) == 0.0
+
+
 @pytest.mark.parametrize("pmode,stride", [(1, 1), (1, 2), (2, 1)])
 def test_padded_coordinate_dma_path_equals_generic_loader(dev, pmode, stride):
     """Reflect (1) / replicate (2) padding with Cin % 64 == 0 runs on the LDS-DMA kernel, which recomputes the padded
