@@ -285,7 +285,16 @@ __global__ void linear_reduce_kernel(const float* __restrict__ partial, int S, i
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * O) return;
   double s = 0.0;
-  for (int z = 0; z < S; ++z) s += (double)partial[(size_t)z * B * O + idx];
+  const size_t stride = (size_t)B * O;
+  int z = 0;
+  for (; z + 8 <= S; z += 8) {              // 8 independent loads in flight (one at a time: 0.4 us per split slice), summed in order
+    float v8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v8[u] = partial[(size_t)(z + u) * stride + idx];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (double)v8[u];
+  }
+  for (; z < S; ++z) s += (double)partial[(size_t)z * stride + idx];
   float v = (float)s + (bias ? bias[idx % O] : 0.f);
   out[idx] = act_apply(act, v, slope);
 }
