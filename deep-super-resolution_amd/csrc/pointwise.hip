@@ -1116,8 +1116,10 @@ extern "C" int dsr_pw_bn_eval_affine(const float* gamma, const float* beta, cons
 }
 extern "C" int dsr_pw_reduce_blocks(size_t P, int* rows_per_block) {
   if (!rows_per_block) return dsr_fail(DSR_E_ARG, "reduce_blocks: null rows_per_block");
-  // enough blocks to fill 256 CUs a few times over, at least 64 rows each
-  static const size_t target = [] { const char* e = getenv("DSR_PW_REDUCE_BLOCKS"); return (size_t)(e ? atoi(e) : 2048); }();
+  // 1024 blocks = the 4 blocks per CU that are resident at once: one round, no tail (measured on the BatchNorm backward
+  // reduction, TB/s of its two operand tensors at 32 x 128 x 128 x 64: 512 blocks 2.8, 1024 4.4, 1536 3.7, 2048 4.2, 4096 3.8);
+  // at least 64 rows each
+  static const size_t target = [] { const char* e = getenv("DSR_PW_REDUCE_BLOCKS"); return (size_t)(e ? atoi(e) : 1024); }();
   size_t rpb = (P + target - 1) / target;
   if (rpb < 64) rpb = 64;
   *rows_per_block = (int)rpb;
