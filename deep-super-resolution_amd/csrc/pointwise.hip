@@ -543,7 +543,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const unsigned short* _
 
 // backward of out = act(scale*y + shift) [+ residual]; g = dout * act'(z).
 // pass 1: per-channel partial sums of g, g*xhat and the PReLU slope gradient sum(dout * z * [z<0]).
-template <int DT, bool NT, int UNR>
+// WITH_P: the launch also forms the PReLU slope gradient (8 more accumulators).  The per-channel scale / shift live in LDS (read
+// per row pair) rather than in 16 registers: with both, the two-rows-in-flight form fits 5 waves per SIMD instead of 4.
+template <int DT, bool NT, int UNR, bool WITH_P>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     const unsigned short* __restrict__ dout, const unsigned short* __restrict__ y, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd, size_t P, int Cp,
@@ -557,19 +559,25 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
   // slot 1 holds sum g*y (the raw conv output), not sum g*xhat: xhat = (y - mean) * rstd is affine in y, so the finalize
   // kernel forms sum g*xhat = rstd * (sum g*y - mean * sum g) in double precision and this kernel keeps two parameter
   // arrays less in registers (134 -> under 100 VGPRs: 3 -> 5 waves per SIMD)
-  float sg[8], sgx[8], sp[8];
-  float csc[8], csh[8];
+  float sg[8], sgx[8];
+  [[maybe_unused]] float sp[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) sg[k] = sgx[k] = sp[k] = 0.f;
-  load8(scale, ch * 8, csc);
-  load8(shift, ch * 8, csh);
+  float* s_aff = red;                                   // [2][Cp] in front of the reduction rows (the block-end reduction starts behind a barrier)
+  for (int c = tid; c < Cp; c += 256) {
+    s_aff[c] = scale[c];
+    s_aff[Cp + c] = shift[c];
+  }
+  __syncthreads();
   size_t p0 = (size_t)blockIdx.x * rows_per_block;
   size_t p1 = p0 + rows_per_block;
   if (p1 > P) p1 = P;
   auto accum = [&](const U4& vd, const U4& vy) {
-    float d[8], f[8];
+    float d[8], f[8], csc[8], csh[8];
     unpack8<DT>(vd, d);
     unpack8<DT>(vy, f);
+    load8(s_aff, ch * 8, csc);
+    load8(s_aff + Cp, ch * 8, csh);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float z = f[k] * csc[k] + csh[k];
@@ -577,7 +585,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
       const float gg = d[k] * act_grad_from_out(act, (act == DSR_ACT_LEAKY || act == DSR_ACT_PRELU) ? z : o, slope);
       sg[k] += gg;
       sgx[k] += gg * f[k];
-      if (act == DSR_ACT_PRELU && z < 0.f) sp[k] += d[k] * z;
+      if constexpr (WITH_P)
+        if (z < 0.f) sp[k] += d[k] * z;
     }
   };
   if (rr < rpi) {
@@ -601,11 +610,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
       accum(ld16<NT>(dout + o0), ld16<NT>(y + o0));
     }
   }
+  __syncthreads();                                      // every thread is done with the scale / shift rows
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     red[tid * 24 + k] = sg[k];
     red[tid * 24 + 8 + k] = sgx[k];
-    red[tid * 24 + 16 + k] = sp[k];
+    red[tid * 24 + 16 + k] = WITH_P ? sp[k] : 0.f;
   }
   __syncthreads();
   for (int c = tid; c < 3 * Cp; c += 256) {
@@ -1171,16 +1181,21 @@ extern "C" int dsr_pw_bn_act_bwd_reduce(int dtype, const void* dout, const void*
   DSR_REQUIRE(dout && y && scale && shift && mean && rstd && partial && DSR_DTYPE_OK(dtype) && P > 0 && DSR_CP_OK(Cp) && blocks > 0 && rpb > 0, "bn_act_bwd_reduce: null pointer or bad shape");
   DSR_REQUIRE(act != DSR_ACT_PRELU || prelu, "bn_act_bwd_reduce: PReLU needs its weight pointer");
   static const int unr = [] { const char* e = getenv("DSR_PW_REDUCE_UNROLL"); return e ? atoi(e) : 2; }();
-#define LAUNCH_RED(NTV, U)                                                                                                  \
-  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DT, NTV, U>), dim3(blocks), dim3(256), 0, st,               \
+#define LAUNCH_RED2(NTV, U, WP)                                                                                             \
+  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DT, NTV, U, WP>), dim3(blocks), dim3(256), 0, st,           \
                                       (const unsigned short*)dout, (const unsigned short*)y, scale, shift, mean, rstd, P, \
                                       Cp, rpb, act, slope, prelu, partial))
+#define LAUNCH_RED(NTV, U)                              \
+  do {                                                  \
+    if (act == DSR_ACT_PRELU) { LAUNCH_RED2(NTV, U, true); } else { LAUNCH_RED2(NTV, U, false); } \
+  } while (0)
   if (pw_nontemporal(P, Cp)) {
     if (unr == 2) { LAUNCH_RED(true, 2); } else { LAUNCH_RED(true, 1); }
   } else {
     if (unr == 2) { LAUNCH_RED(false, 2); } else { LAUNCH_RED(false, 1); }
   }
 #undef LAUNCH_RED
+#undef LAUNCH_RED2
   return dsr_launch_status("dsr_pw_bn_act_bwd_reduce");
 }
 extern "C" int dsr_pw_bn_bwd_finalize(const float* partial, int blocks, int C, int Cp, float count, const float* mean,

@@ -9,6 +9,7 @@ PyTorch is only plumbing here: it owns device memory, the stream and the autogra
 FLOP is a HIP kernel from csrc/.  Nothing in this file can run without the extension.
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -168,6 +169,19 @@ def _reduce_blocks(p):
     rpb = C.c_int()
     blocks = _lib.lib().dsr_pw_reduce_blocks(p, C.byref(rpb))
     return blocks, rpb.value
+
+
+_BN_BWD_BLOCKS = int(os.environ.get("DSR_PW_BN_REDUCE_BLOCKS", "1280"))
+
+
+def _bn_bwd_blocks(p, act):
+    """Grid of dsr_pw_bn_act_bwd_reduce.  Without the PReLU slope gradient the kernel fits five waves per SIMD: 1280 blocks
+    (five per CU, all resident at once) stream 10-20 % faster than the 1024 of the other row reductions
+    (tools/microbench_pw.py); the PReLU form (four waves per SIMD) keeps the common grid."""
+    if act == ACT_PRELU:
+        return _reduce_blocks(p)
+    rpb = max(64, -(-p // _BN_BWD_BLOCKS))
+    return -(-p // rpb), rpb
 
 
 _wgrad_batch = None      # the open batched_wgrad context (per process: backward passes are issued from one thread here)
@@ -575,7 +589,7 @@ class ConvBNAct(torch.autograd.Function):
         dgamma = torch.empty(cout, dtype=torch.float32, device=dev)
         dbeta = torch.empty(cout, dtype=torch.float32, device=dev)
         dprelu = torch.empty(1, dtype=torch.float32, device=dev) if prelu is not None else None
-        blocks, rpb = _reduce_blocks(p)
+        blocks, rpb = _bn_bwd_blocks(p, ctx.act)
         part = torch.empty((blocks + _scr()) * 3 * cp, dtype=torch.float32, device=dev)
         check(lib.dsr_pw_bn_act_bwd_reduce(_dt(x), _ptr(dout), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean),
                                            _ptr(rstd), p, cp, blocks, rpb, ctx.act, slope, _ptr(prelu), _ptr(part),
@@ -1137,7 +1151,7 @@ class BNAct(torch.autograd.Function):
         c2 = torch.empty(cp, dtype=torch.float32, device=dev)
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
-        blocks, rpb = _reduce_blocks(p)
+        blocks, rpb = _bn_bwd_blocks(p, ctx.act)
         part = torch.empty((blocks + _scr()) * 3 * cp, dtype=torch.float32, device=dev)
         check(lib.dsr_pw_bn_act_bwd_reduce(_dt(x), _ptr(dout), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
                                            p, cp, blocks, rpb, ctx.act, slope, None, _ptr(part), _stream()))
