@@ -526,11 +526,8 @@ static void c64_launch(const C64Args& a, dim3 grid, hipStream_t st) {
   constexpr int LDS = c64_lds_bytes(TR);
   auto* fn = conv_c64_kernel<DT, MODE, TR>;
   if constexpr (LDS > 64 * 1024) {
-    static bool done = false;       // more than 64 KB of dynamic LDS needs the opt-in, once per kernel (not a stream operation)
-    if (!done) {
-      (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      done = true;
-    }
+    static LdsOptIn optin;          // more than 64 KB of dynamic LDS needs the opt-in, once per kernel and device (not a stream operation)
+    optin.ensure((const void*)fn, LDS);
   }
   hipLaunchKernelGGL(fn, grid, dim3(256), LDS, st, a);
 }

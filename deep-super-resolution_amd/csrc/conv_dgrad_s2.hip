@@ -249,12 +249,9 @@ void dsr_launch_dgrad_s2(DgradS2Args& a, int N, int dtype, hipStream_t st) {
   a.dx_bytes = (unsigned)((size_t)N * a.H * a.W * a.CinP * 2);
   const int ntiles = a.tiles_m * a.ci_blocks;
   const int blocks = ntiles < 256 ? ntiles : 256;          // persistent: one 8-wave block per CU (128 KB of LDS each)
-  static bool attr_done = false;
-  if (!attr_done) {       // more than 64 KB of dynamic LDS needs the opt-in, once per kernel (not a stream operation)
-    (void)hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS);
-    (void)hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS);
-    attr_done = true;
-  }
+  static LdsOptIn optin[2];   // more than 64 KB of dynamic LDS needs the opt-in, once per kernel and device (not a stream operation)
+  optin[0].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_BF16>, S2_LDS);
+  optin[1].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_F16>, S2_LDS);
   if (dtype == DSR_DTYPE_BF16)
     hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_BF16>), dim3(blocks), dim3(512), S2_LDS, st, a);
   else

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 256 * 25
             if constexpr (ST) {
               const float vm = (rok && cok[j]) ? v : 0.f;   // statistics ignore tail rows / pad columns
               s1[j] += vm;
-              s2[j] = __builtin_fmaf(vm, vm, s2[j]);        // (explicit: conv_gemm_big.hip must round identically)
+              s2[j] = __builtin_fmaf(vm, vm, s2[j]);
             }
             o[j] = cok[j] ? actf(v) : 0.f;
           }
@@ -727,11 +727,8 @@ static void launch_swap(dim3 grid, const ConvGemmArgs& b, hipStream_t st) {
   constexpr int LDS = ConvGemmLds<BM, BN, WGM, NSTAGE>::TOTAL;
   auto* fn = conv_gemm_kernel<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE, SWAP, PADX>;
   if constexpr (LDS > 64 * 1024) {   // more than 64 KB of dynamic LDS needs the opt-in, once per kernel (not a stream op)
-    static bool done = false;
-    if (!done) {
-      (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      done = true;
-    }
+    static LdsOptIn optin;
+    optin.ensure((const void*)fn, LDS);
   }
   hipLaunchKernelGGL(fn, grid, dim3(64 * WGM * WGN), LDS, st, b);
 }
@@ -817,7 +814,6 @@ static void dispatch_dt(const ConvGemmArgs& a, hipStream_t st) {
 void dsr_launch_conv_gemm(const ConvGemmArgs& a, int dtype, hipStream_t st) {
   if (!a.mask_x) {          // (the persistent kernels keep a DMA in flight across their epilogue: no masked form)
     if (dsr_launch_conv_gemm_persist(a, dtype, st)) return;   // many-tile fast-path launches: persistent kernel
-    if (dsr_launch_conv_gemm_big(a, dtype, st)) return;       // 256x256 tiles, more tiles than CUs: persistent form
   }
   if (dtype == DSR_DTYPE_BF16)
     dispatch_dt<DSR_DTYPE_BF16>(a, st);

@@ -379,11 +379,8 @@ static void launch_p(const ConvGemmArgs& b, int blocks, hipStream_t st) {
   constexpr int LDS = 2 * (128 * 128 + BN * 128) + 2 * 2 * BN * 4 + DSR_MAX_TAPS * 4;
   auto* fn = conv_gemm_persist_kernel<DT, BN, SWAP>;
   if constexpr (LDS > 64 * 1024) {
-    static bool done = false;
-    if (!done) {
-      (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      done = true;
-    }
+    static LdsOptIn optin;
+    optin.ensure((const void*)fn, LDS);
   }
   hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), LDS, st, b);
 }

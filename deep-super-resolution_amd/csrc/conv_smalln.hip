@@ -311,7 +311,7 @@ __global__ void zero_pad_channels_kernel(unsigned short* __restrict__ y, size_t 
   for (int c = cout; c < CoutP; ++c) y[p * CoutP + c] = 0;
 }
 
-static bool g_smalln_attr_set[4] = {false, false, false, false};
+static LdsOptIn g_smalln_optin[4];
 
 int dsr_launch_conv_smalln(SmallNArgs& a, int N, int dtype, hipStream_t st) {
   a.tiles_y = (a.OH + 7) / 8;
@@ -328,21 +328,15 @@ int dsr_launch_conv_smalln(SmallNArgs& a, int N, int dtype, hipStream_t st) {
                    : di == 1 ? (const void*)conv_smalln_kernel<DSR_DTYPE_F16, 9>
                    : di == 2 ? (const void*)conv_smalln_kernel<DSR_DTYPE_BF16, 3>
                              : (const void*)conv_smalln_kernel<DSR_DTYPE_F16, 3>;
-  if (!g_smalln_attr_set[di]) {   // > 64 KB of dynamic LDS needs the opt-in once per kernel (not a stream operation)
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    g_smalln_attr_set[di] = true;
-  }
+  g_smalln_optin[di].ensure(fn, 160 * 1024);   // > 64 KB of dynamic LDS needs the opt-in once per kernel and device (not a stream operation)
   const size_t P = (size_t)N * a.OH * a.OW;
   const bool zpad = !a.out_f32 && a.cout < a.CoutP;
   if (a.KW == 9 && a.KH == 9 && a.cout <= 3 && a.pad == 4 && !a.flip) {   // the generator's tail: Toeplitz mapping
-    static bool attr_done[2] = {false, false};
+    static LdsOptIn toeplitz_optin[2];
     const int dj = dtype == DSR_DTYPE_BF16 ? 0 : 1;
     const size_t tl = 18 * 16 * 128 + 16 * 40 * 128;
     const void* tf = dj == 0 ? (const void*)conv_toeplitz9_kernel<DSR_DTYPE_BF16> : (const void*)conv_toeplitz9_kernel<DSR_DTYPE_F16>;
-    if (!attr_done[dj]) {
-      (void)hipFuncSetAttribute(tf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_done[dj] = true;
-    }
+    toeplitz_optin[dj].ensure(tf, 160 * 1024);
     dim3 tg(a.ntiles < 256 ? a.ntiles : 256);
     if (dj == 0) {
       hipLaunchKernelGGL((conv_toeplitz9_kernel<DSR_DTYPE_BF16>), tg, block, tl, st, a);

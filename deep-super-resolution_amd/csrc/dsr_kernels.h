@@ -82,7 +82,6 @@ static inline bool dsr_conv_gemm_use_256(long long M, int NB, bool fast, bool st
 }
 
 bool dsr_launch_conv_gemm_persist(const ConvGemmArgs& a, int dtype, hipStream_t st);   // conv_gemm_persist.hip
-bool dsr_launch_conv_gemm_big(const ConvGemmArgs& a, int dtype, hipStream_t st);       // conv_gemm_big.hip
 
 struct WgradArgs {
   const void* x;    // [N][IH][IW][CinP]
@@ -220,6 +219,23 @@ struct FirstBwdArgs {
 
 void dsr_launch_wgrad_reduce(const float* partial, float* dw, int splits, int ntaps, int Cout, int Cin, int CoutP,
                              int CinP, hipStream_t st);
+
+// Opt-in for more than 64 KB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize): a property of (kernel, DEVICE), so
+// the "already done" flag is one bit per device ordinal, and the launchers may be entered from the main and the autograd
+// thread at once, so it is atomic.  One static LdsOptIn per kernel instantiation; setting the attribute twice is harmless.
+#include <atomic>
+struct LdsOptIn {
+  std::atomic<unsigned long long> done{0};
+  void ensure(const void* fn, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      done.fetch_or(bit, std::memory_order_release);
+    }
+  }
+};
 
 // records hipGetLastError() under `what`; returns 0 or a negative code (see dsr_last_error()).
 int dsr_launch_status(const char* what);

@@ -40,10 +40,14 @@ def load_model(model, model_path):
 
 
 def psnr(pred, target, data_range=None):
-    """Host float: 10*log10(range^2 / MSE(pred, target)) for fp32 NCHW device tensors."""
+    """Host float: 10*log10(range^2 / MSE(pred, target)) for fp32 NCHW device tensors.
+    ``data_range=None`` follows what torchmetrics' ``PeakSignalNoiseRatio()`` (eval_GAN.py:30,47: the metric is CALLED per
+    image, which evaluates that image from the metric's default state) does as far as its published behaviour goes: the range
+    is max(target.max(), 0) - min(target.min(), 0) -- its running minimum and maximum start at 0, so a [0.2, 0.9] target has
+    range 0.9, not 0.7.  torchmetrics is absent from /root/reference and from this image: PARITY UNPINNED."""
     mse = float(F.mse_loss(pred.detach(), target.detach()))
     if data_range is None:
-        data_range = float(target.max() - target.min())
+        data_range = max(float(target.max()), 0.0) - min(float(target.min()), 0.0)
     return 10.0 * math.log10(data_range ** 2 / mse) if mse > 0 else float("inf")
 
 

@@ -201,9 +201,12 @@ class batched_wgrad:
     .grad is already set is therefore computed at once, unbatched.  On exit each parameter's .grad is checked to be the
     tensor the launch wrote (autograd may have cloned it) and repaired if not."""
 
+    MAX_PROBLEMS = 256           # kMaxBatchProblems of dsr_conv_wgrad_batched: larger groups are split in flush()
+
     def __init__(self, enabled=True):
         self.enabled = enabled
-        self.items = {}          # id(weight) -> [weight, returned tensor, alias of it, [(desc, x, dy), ...]]
+        self.items = {}          # id(weight) -> [weight, returned tensor, alias of it, [(desc, x, dy), ...], [extra addends]]
+        self.unbatched = set()   # id(weight) of weights that already returned a REAL gradient inside this block
 
     def __enter__(self):
         global _wgrad_batch
@@ -218,7 +221,15 @@ class batched_wgrad:
             _wgrad_batch = None
             if et is None:
                 self.flush()
+            else:
+                # backward raised: the launch never ran, so a .grad that autograd already pointed at one of the placeholder
+                # tensors holds uninitialised memory -- drop it rather than leave garbage behind
+                for weight, _, alias, _, _ in self.items.values():
+                    g = weight.grad
+                    if g is not None and g.data_ptr() == alias.data_ptr():
+                        weight.grad = None
             self.items = {}
+            self.unbatched = set()
         return False
 
     def add(self, weight, desc, x, dy, wshape):
@@ -230,8 +241,20 @@ class batched_wgrad:
         dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
         # (the alias shares dw's storage through a tensor object of its own: autograd takes over a gradient only while
         # nobody else holds the very tensor it was handed)
-        self.items[id(weight)] = [weight, None, dw.detach(), [(desc, x, dy)]]
+        self.items[id(weight)] = [weight, None, dw.detach(), [(desc, x, dy)], []]
         return dw
+
+    def add_unbatchable(self, weight, dw):
+        """A use of `weight` that the grouped launch cannot take (other stride / padding ...), computed at once as `dw`.  If an
+        earlier use of the same weight joined the batch, autograd already holds its PLACEHOLDER: summing a real tensor into it
+        would add garbage, and the later launch would overwrite the sum.  The real contribution is therefore kept here and
+        added to the launch's result in flush(); the caller returns None for this use.  Returns True when that happened."""
+        ent = self.items.get(id(weight))
+        if ent is None:
+            self.unbatched.add(id(weight))       # later batchable uses of this weight must not join the batch either
+            return False
+        ent[4].append(dw)
+        return True
 
     def flush(self):
         if not self.items:
@@ -241,9 +264,20 @@ class batched_wgrad:
         by_dtype = {}
         for ent in ents:
             by_dtype.setdefault(ent[3][0][0].dtype, []).append(ent)
-        for group in by_dtype.values():
+        groups = []
+        for group in by_dtype.values():      # at most MAX_PROBLEMS problems per launch; the uses of one weight stay together
+            cur, ncur = [], 0
+            for ent in group:
+                if cur and ncur + len(ent[3]) > self.MAX_PROBLEMS:
+                    groups.append(cur)
+                    cur, ncur = [], 0
+                cur.append(ent)
+                ncur += len(ent[3])
+            if cur:
+                groups.append(cur)
+        for group in groups:
             descs, xs, dys, dws = [], [], [], []
-            for weight, _, alias, uses in group:
+            for weight, _, alias, uses, _ in group:
                 for desc, x, dy in uses:
                     descs.append(desc)
                     xs.append(x.data_ptr())
@@ -262,7 +296,9 @@ class batched_wgrad:
                 e1.record()
                 KERNEL_LOG.append(("wgrad_batch", [(d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad) for d in descs],
                                    e0, e1, "conv_wgrad_dma_batch_kernel"))
-        for weight, _, alias, uses in ents:
+        for weight, _, alias, uses, extra in ents:
+            for e in extra:                               # contributions of uses the grouped launch could not take
+                alias.add_(e)
             g = weight.grad
             if g is None:
                 continue                                  # (nobody kept the gradient: e.g. torch.autograd.grad)
@@ -309,6 +345,7 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape, weight=None,
     if addend is not None:
         dx = addend if dx is None else dx + addend
     if (need_dw and _wgrad_batch is not None and weight is not None and weight.grad is None
+            and id(weight) not in _wgrad_batch.unbatched                      # (an earlier use returned a real gradient)
             and not getattr(weight, "_post_accumulate_grad_hooks", None)      # (a hook would read the gradient at once)
             and lib.dsr_conv_wgrad_batchable(C.byref(desc))):
         return dx, _wgrad_batch.add(weight, desc, x, dy, weight_shape)
@@ -318,6 +355,8 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape, weight=None,
         ws = torch.empty(wsz, dtype=torch.uint8, device=x.device)
         check(_timed("wgrad", desc, lambda: lib.dsr_conv_wgrad(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), wsz,
                                                                  _stream())))
+        if _wgrad_batch is not None and weight is not None and _wgrad_batch.add_unbatchable(weight, dw):
+            dw = None            # joins the batched contribution of the same weight when the block exits
     return dx, dw
 
 
@@ -522,16 +561,22 @@ class ConvBNAct(torch.autograd.Function):
                                          _ptr(running_mean), _ptr(running_var), _ptr(nbt), BN_MOMENTUM, BN_EPS,
                                          int(cfg.get("bn_updates", 1)),
                                          _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
+            bump(running_mean)       # rewritten through their raw pointers: whatever is keyed on them (the inference
+            bump(running_var)        # affine map kept with running_mean, below) must see a new version
         else:
             infer = cfg.get("infer", False) and lib.dsr_conv_fwd_affine_supported(C.byref(desc))
             # inference: the affine map of an eval-mode BatchNorm changes only when its four tensors do -- keep it with the
             # running mean, keyed by their version counters (33 launches of ~3 us per x8 forward otherwise)
-            key = (gamma._version, beta._version, running_mean._version, running_var._version, str(dev))
-            hit = getattr(running_mean, "_dsr_affine", None) if infer else None
+            # (_version(p) = torch's counter + the counter bump() advances when a HIP launch rewrites p through its raw
+            #  pointer -- FusedAdam for gamma / beta, the train-mode finalize below for the running statistics -- + the address)
+            key = (_version(gamma), _version(beta), _version(running_mean), _version(running_var), str(dev))
             capturing = torch.cuda.is_current_stream_capturing()
+            # a capture never takes the kept map: the graph would replay yesterday's scale / shift whatever the statistics
+            # are by then -- inside a graph the affine launch is part of every replay
+            hit = getattr(running_mean, "_dsr_affine", None) if (infer and not capturing) else None
             if hit is not None and hit[0] == key:
                 scale, shift = hit[1], hit[2]
-                if hit[4] != torch.cuda.current_stream(dev).cuda_stream and not capturing:
+                if hit[4] != torch.cuda.current_stream(dev).cuda_stream:
                     torch.cuda.current_stream(dev).wait_event(hit[3])      # computed on another stream
             else:
                 check(lib.dsr_pw_bn_eval_affine(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), BN_EPS,
@@ -1127,6 +1172,8 @@ class BNAct(torch.autograd.Function):
                                          _ptr(running_mean), _ptr(running_var), _ptr(nbt), BN_MOMENTUM, BN_EPS,
                                          int(cfg.get("bn_updates", 1)),
                                          _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))
+            bump(running_mean)
+            bump(running_var)
         else:
             check(lib.dsr_pw_bn_eval_affine(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), BN_EPS, c,
                                             cp, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _stream()))

@@ -7,6 +7,16 @@ fixed answer.  This context manager answers it per test: inside it, every convol
 input, weight and output (and, in backward, the gradients flowing through those points) to the given 16-bit
 type -- an idealised restatement of the product's storage policy with the oracle's own arithmetic.  Tests then
 require   |hip - fp32 oracle|  <=  c * |16-bit-storage oracle - fp32 oracle| + eps.
+
+What is modelled, exactly (pinned by tests/test_oracle_golden.py::test_lowp_storage_rounds_exactly_the_stated_points):
+  * F.conv2d: input, weight and output rounded to `dtype` (round-to-nearest-even, the cast torch does); in backward the
+    gradients arriving at those three points are rounded the same way; the bias and the accumulation stay fp32;
+  * F.linear (the discriminator's dense head): input and weight rounded (the product feeds the dense head 16-bit activations
+    and a 16-bit shadow of the fp32 weights); its OUTPUT stays fp32, as the product's does.
+What is NOT modelled: the 16-bit stores after BatchNorm / activation passes (their outputs are rounded once more where the
+next convolution reads them -- that rounding IS modelled, as the next conv's input rounding), BatchNorm statistics (fp32 on
+both sides), Adam (fp32 on both sides).  The floor is therefore a LOWER bound of what an implementation with the product's
+storage policy can reach, which is the direction the tests need.
 """
 import contextlib
 
@@ -32,7 +42,10 @@ def storage(dtype):
     def conv(inp, w, b=None, *a, **kw):
         return _Round.apply(orig_conv(_Round.apply(inp, dtype), _Round.apply(w, dtype), b, *a, **kw), dtype)
 
-    F.conv2d = conv
+    def linear(inp, w, b=None):
+        return orig_lin(_Round.apply(inp, dtype), _Round.apply(w, dtype), b)
+
+    F.conv2d, F.linear = conv, linear
     try:
         yield
     finally:

@@ -168,6 +168,42 @@ def test_inference_affine_cache_follows_the_statistics(dev):
     assert (y2.cpu() - yr).abs().max().item() <= 0.06
 
 
+def test_inference_affine_cache_follows_training_steps(dev):
+    """infer.super_resolve is meant to be called mid-training (it toggles eval() and restores train()): eval forward (fills
+    the kept affine maps) -> three gen_l1_step (FusedAdam rewrites gamma / beta, the train-mode finalize rewrites the running
+    statistics, all through raw pointers: torch's _version counters never move) -> eval forward.  The second eval forward
+    must apply the NEW statistics: it is compared with the oracle's eval forward of the oracle's state after the same three
+    steps, and must differ from a forward with the stale maps."""
+    optim, steps = P("optim"), P("steps")
+    g, sd = build(dev, 4, 2)
+    lr = filler.tensor("in:cache_lr", (4, 3, 24, 24), 0.5, 0.5)
+    hr = filler.tensor("in:cache_hr", (4, 3, 96, 96))
+    x = filler.tensor("in:cache_x", (1, 3, 24, 24), 0.5, 0.5)
+    g.eval()
+    with torch.no_grad():
+        y0 = g(x.to(dev))
+    bn = g.residual_blocks[0].bn1
+    stale = bn.running_mean._dsr_affine
+    assert stale is not None
+    g.train()
+    # a large learning rate so that three steps move gamma / beta far enough to tell stale maps from fresh ones
+    opt = optim.FusedAdam(g.parameters(), lr=2e-2)
+    st = recipes.GenOnlyState({k: v.clone() for k, v in sd.items()}, lr=2e-2)
+    for _ in range(3):
+        steps.gen_l1_step(g, opt, lr.to(dev), hr.to(dev))
+        recipes.gen_l1_step(st, lr, hr)
+    g.eval()
+    with torch.no_grad():
+        y1 = g(x.to(dev))
+    torch.cuda.synchronize()
+    assert bn.running_mean._dsr_affine[0] != stale[0]                 # the key moved with the raw-pointer rewrites
+    yr = gan.generator_forward(st.g, x, False)
+    yr0 = gan.generator_forward(sd, x, False)
+    assert (yr - yr0).abs().max().item() > 0.2                         # the three steps changed the network's output a lot
+    assert (y1.cpu() - yr).abs().max().item() <= 0.06, (y1.cpu() - yr).abs().max().item()
+    assert (y0.cpu() - yr0).abs().max().item() <= 0.06
+
+
 def test_gen_l1_trajectory(dev):
     """BASELINE config-2 step recipe: 4 Adam steps, PSNR delta vs the fp32 oracle <= 0.02 dB."""
     optim, steps = P("optim"), P("steps")

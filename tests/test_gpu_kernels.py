@@ -615,12 +615,32 @@ def test_conv_256x256_tile_equals_128x128(dev, op):
                 os.environ[k] = v
     torch.cuda.synchronize()
     assert torch.isfinite(outs[0].float()).all()
-    assert torch.equal(outs[0], outs[1])
+    if os.environ.get("DSR_CONV_STREAMK", "1") == "0" or op == "dgrad_s2":
+        assert torch.equal(outs[0], outs[1])
+    else:
+        # a launch whose tiles do not fill whole rounds of the chip runs the 256x256 tile as stream-K pieces: the K range of a
+        # tile is then summed in two or more fp32 pieces, so the last bit of an accumulator may differ from the 128x128 tile's
+        assert rel_err(outs[1].float(), outs[0].float()) <= 2.0 ** -7
+    # ---- and against a plain fp32 PyTorch reference of the same op on the same bf16 operands, at THIS shape (the one that
+    # dispatches to the 256x256 tile): one bf16 rounding of the output = 2^-9 relative to the value, stated relative to the
+    # tensor's maximum as everywhere in this file
+    xr, wr, dyr = x.float().cpu().permute(0, 3, 1, 2), wt.to(torch.bfloat16).float().cpu(), dy.float().cpu().permute(0, 3, 1, 2)
+    if op in ("fwd", "fwd_stats"):
+        pre = TF.conv2d(xr, wr, bias.cpu(), stride=stride, padding=1)
+        ref = torch.relu(pre) if op == "fwd" else pre
+    else:
+        ref = TF.conv_transpose2d(dyr, wr, stride=stride, padding=1, output_padding=(h + 2 - 3) % stride if stride > 1 else 0)
+    for o in outs:
+        got = o.float().cpu().permute(0, 3, 1, 2)
+        assert got.shape == ref.shape
+        assert rel_err(got, ref) <= 1.2e-2
     if stats:    # same fp32 accumulators, summed in a different order (channel-major vs pixel-major epilogue)
         assert torch.isfinite(stats[0]).all()
-        assert float((stats[0] - stats[1]).abs().max() / stats[0].abs().max()) < 1e-6
-        ref = torch.stack([outs[0].float().double().sum((0, 1, 2)), (outs[0].float().double() ** 2).sum((0, 1, 2))])
-        assert float((stats[1] - ref).abs().max() / ref.abs().max()) < 2e-3      # (y is the bf16-rounded accumulator)
+        assert float((stats[0] - stats[1]).abs().max() / stats[0].abs().max()) < 1e-5
+        # per-channel sum / sum of squares of the REFERENCE's pre-activation output (fp32 conv on the CPU), not of the kernel's own
+        ref_st = torch.stack([pre.double().sum((0, 2, 3)), (pre.double() ** 2).sum((0, 2, 3))])
+        for s in stats:
+            assert float((s.cpu() - ref_st).abs().max() / ref_st.abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 64, 96, 64, 64), (1, 50, 38, 128, 192), (3, 32, 32, 256, 64)])
@@ -730,61 +750,46 @@ def test_conv_wgrad_batched_equals_per_layer_launches(dev):
         assert float((got - per_layer.cpu().double()).abs().max()) < 2e-5 * scale + 1e-4, i
 
 
-@pytest.mark.parametrize("op", ["fwd", "fwd_stats", "dgrad"])
-def test_conv_256x256_persistent_equals_one_tile_per_block(dev, op):
-    """conv_gemm_big_kernel (the 256x256 tile as persistent blocks that start the next tile's DMA before their output stores;
-    conv_gemm_big.hip) against conv_gemm_kernel<256x256> on a launch with 640 tiles on 256 CUs (2.5 tiles per block: blocks with
-    two and with three tiles, both LDS stages in the C-staging role): same K order and the same epilogue arithmetic => outputs
-    bit for bit, statistics to 1e-6.  The persistent form is an opt-in experiment (DSR_CONV_BIG_PERSIST=1; measured slower)."""
+def test_conv_wgrad_batched_trunk_sized_group_vs_float64(dev):
+    """The grouped weight-gradient launch at the problem COUNT and map sizes of a real backward pass (the generator's
+    backward groups 35 problems; here 34: 30 trunk-shaped 64 -> 64 layers on 64x64 maps, a 64 -> 256 PixelShuffle-conv
+    shape on 96x80, a 64 -> 128 and a 128 -> 256 layer, and one weight applied to two batches) against a float64
+    torch.nn.grad.conv2d_weight of the same bf16 operands: fp32 accumulation of exact products, 2e-5 of the tensor's maximum."""
     import ctypes as C
-    import os
     L = P("_lib")
     lib = L.lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    n, h, w, cin, cout = 5, 128, 128, 64, 512            # M = 81,920 = 320 x 256; two column tiles
-    if op == "dgrad":
-        cin, cout = 512, 64
-    d = L.ConvDesc(L.BF16, n, h, w, cin, cout, 3, 3, 1, 1, 0)
-    g = torch.Generator(device="cpu").manual_seed(17)
-    wt = ((torch.rand(cout, cin, 3, 3, generator=g) - 0.5) * 0.1).to(dev)
-    wf = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 0), dtype=torch.bfloat16, device=dev)
-    wd = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 1), dtype=torch.bfloat16, device=dev)
-    L.check(lib.dsr_conv_pack_weight(C.byref(d), wt.data_ptr(), wf.data_ptr(), wd.data_ptr(), st))
-    x = (torch.rand(n, h, w, cin, generator=g) - 0.5).to(torch.bfloat16).to(dev)
-    dy = (torch.rand(n, h, w, cout, generator=g) - 0.5).to(torch.bfloat16).to(dev)
-    bias = (torch.rand(cout, generator=g) - 0.5).to(dev)
-    outs, stats = [], []
-    old = os.environ.get("DSR_CONV_BIG_PERSIST")
-    try:
-        for mode in ("0", "1"):
-            os.environ["DSR_CONV_BIG_PERSIST"] = mode
-            if op != "dgrad":
-                y = torch.full((n, h, w, cout), float("nan"), dtype=torch.bfloat16, device=dev)
-                rows = lib.dsr_conv_stats_rows(C.byref(d))
-                part = torch.full(((rows + 64) * 2 * cout,), float("nan"), dtype=torch.float32, device=dev)
-                ep = L.Epilogue(L.ACT_LEAKY if op == "fwd" else L.ACT_NONE, 0.2, None, bias.data_ptr(),
-                                part.data_ptr() if op == "fwd_stats" else None, 0, None)
-                assert "256x256" in lib.dsr_conv_kernel_name(C.byref(d), 0, C.byref(ep)).decode()
-                L.check(lib.dsr_conv_fwd(C.byref(d), x.data_ptr(), wf.data_ptr(), C.byref(ep), y.data_ptr(), st))
-                outs.append(y)
-                if op == "fwd_stats":
-                    stats.append(part[:rows * 2 * cout].clone())
-            else:
-                dx = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
-                assert "256x256" in lib.dsr_conv_kernel_name(C.byref(d), 1, None).decode()
-                L.check(lib.dsr_conv_dgrad(C.byref(d), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), None, 0, st))
-                outs.append(dx)
-    finally:
-        if old is None:
-            os.environ.pop("DSR_CONV_BIG_PERSIST", None)
-        else:
-            os.environ["DSR_CONV_BIG_PERSIST"] = old
+    g = torch.Generator(device="cpu").manual_seed(23)
+    shapes = [(2, 64, 64, 64, 64)] * 30 + [(1, 96, 80, 64, 256), (2, 72, 64, 64, 128), (1, 64, 64, 128, 256)]
+    descs, xs, dys, dws, refs = [], [], [], [], []
+    for i, (n, h, w, cin, cout) in enumerate(shapes):
+        uses = 2 if i == 3 else 1
+        dw = torch.full((cout, cin, 3, 3), float("nan"), dtype=torch.float32, device=dev)
+        ref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64)
+        for u in range(uses):
+            x = bfr(torch.rand(n + u, cin, h, w, generator=g) - 0.5)
+            dy = bfr(torch.rand(n + u, cout, h, w, generator=g) - 0.5)
+            ref += torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dy.double(), padding=1)
+            descs.append(L.ConvDesc(L.BF16, n + u, h, w, cin, cout, 3, 3, 1, 1, 0))
+            xs.append(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev))
+            dys.append(dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev))
+            dws.append(dw)
+        refs.append((dw, ref))
+    k = len(descs)
+    assert k == 34 and k > 30
+    darr = (L.ConvDesc * k)(*descs)
+    xa = (C.c_void_p * k)(*[t.data_ptr() for t in xs])
+    ya = (C.c_void_p * k)(*[t.data_ptr() for t in dys])
+    wa = (C.c_void_p * k)(*[t.data_ptr() for t in dws])
+    wsz = lib.dsr_conv_wgrad_batched_workspace(k, darr, wa)
+    assert wsz > 0
+    ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+    L.check(lib.dsr_conv_wgrad_batched(k, darr, xa, ya, wa, ws.data_ptr(), wsz, st))
     torch.cuda.synchronize()
-    assert torch.isfinite(outs[1].float()).all()
-    assert torch.equal(outs[0], outs[1])
-    if stats:      # (the persistent kernel sums a tile's statistics in two passes of 64 rows: same values, another order)
-        assert torch.isfinite(stats[1]).all()
-        assert float((stats[0].double() - stats[1].double()).abs().max() / stats[0].double().abs().max()) < 1e-6
+    for i, (dw, ref) in enumerate(refs):
+        got = dw.cpu().double()
+        assert torch.isfinite(got).all(), i
+        assert float((got - ref).abs().max()) < 2e-5 * float(ref.abs().max()) + 1e-4, i
 
 
 def test_conv_dgrad_add_equals_dgrad_then_add(dev):

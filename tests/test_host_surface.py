@@ -281,3 +281,17 @@ def test_act_link_and_batched_wgrad_contexts_without_gpu():
         with F.batched_wgrad():
             raise KeyError("x")
     assert F._wgrad_batch is None
+    # a weight with a batchable and an unbatchable use (bookkeeping only; the launches are GPU tests): the unbatchable use
+    # after a batched one is parked as an addend, the other order keeps the weight out of the batch altogether
+    w1, w2 = torch.zeros(4, 4, 3, 3), torch.zeros(4, 4, 3, 3)
+    xx = torch.zeros(1, 4, 4, 8)
+    with pytest.raises(KeyError):
+        with F.batched_wgrad() as b:
+            ph = b.add(w1, None, xx, xx, (4, 4, 3, 3))
+            assert ph is not None and b.add(w1, None, xx, xx, (4, 4, 3, 3)) is None
+            extra = torch.ones(4, 4, 3, 3)
+            assert b.add_unbatchable(w1, extra) is True and b.items[id(w1)][4] == [extra]
+            assert b.add_unbatchable(w2, extra) is False and id(w2) in b.unbatched
+            w1.grad = ph                                  # what autograd does with the placeholder
+            raise KeyError("backward failed")             # (exit without a launch: needs no GPU)
+    assert w1.grad is None and F._wgrad_batch is None

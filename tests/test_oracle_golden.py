@@ -346,3 +346,53 @@ def test_data_scaling_and_patches():
         cy = rng_b.randint(8 // 2, 24 - 8 // 2)                                           # :129
         assert (top, left) == (int(cy - 8 // 2), int(cx - 16 // 2)) and (htop, hleft) == (top * 4, left * 4)
         assert 0 <= top and top + 8 <= 24 and 0 <= left and left + 16 <= 40
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_lowp_storage_rounds_exactly_the_stated_points(dtype):
+    """oracle/lowp.py is the yardstick six GPU tests measure their bars against, so what it models is pinned here, on the CPU:
+    inside lowp.storage(dtype) a convolution equals the plain fp32 convolution of the ROUNDED input and ROUNDED weight with its
+    output rounded once (bias and accumulation fp32), its three gradients are the plain gradients of that computation with the
+    incoming gradient, the input gradient and the weight gradient rounded; F.linear rounds input and weight (and their
+    gradients) but not its output; outside the context both functions are the stock ones again."""
+    import torch.nn.functional as F
+    from oracle import lowp
+    rd = lambda t: t.to(dtype).to(torch.float32)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5, 9, 11, generator=g)
+    w = torch.randn(7, 5, 3, 3, generator=g) * 0.2
+    b = torch.randn(7, generator=g)
+    go = torch.randn(2, 7, 5, 6, generator=g)
+    stock_conv, stock_lin = F.conv2d, F.linear
+    xs, ws, bs = (t.clone().requires_grad_(True) for t in (x, w, b))
+    with lowp.storage(dtype):
+        assert F.conv2d is not stock_conv and F.linear is not stock_lin
+        y = F.conv2d(xs, ws, bs, stride=2, padding=1)
+        y.backward(go)
+    assert F.conv2d is stock_conv and F.linear is stock_lin
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (rd(x), rd(w), b))
+    yr = F.conv2d(xr, wr, br, stride=2, padding=1)
+    assert torch.equal(y.detach(), rd(yr.detach()))                   # one rounding of the output, nothing else
+    assert not torch.equal(y.detach(), F.conv2d(x, w, b, stride=2, padding=1))          # (and it does change the numbers)
+    yr.backward(rd(go))                                               # the gradient arriving at the output is rounded
+    assert torch.equal(xs.grad, rd(xr.grad)) and torch.equal(ws.grad, rd(wr.grad))      # ... and so are the two leaving
+    assert torch.equal(bs.grad, br.grad)                              # bias gradient: fp32 sum of the rounded output gradient
+    # dense head: input and weight rounded, output fp32
+    a = torch.randn(3, 20, generator=g)
+    m = torch.randn(4, 20, generator=g)
+    c = torch.randn(4, generator=g)
+    gl = torch.randn(3, 4, generator=g)
+    a_s, m_s = a.clone().requires_grad_(True), m.clone().requires_grad_(True)
+    with lowp.storage(dtype):
+        z = F.linear(a_s, m_s, c)
+        z.backward(gl)
+    ar, mr = rd(a).requires_grad_(True), rd(m).requires_grad_(True)
+    zr = F.linear(ar, mr, c)
+    assert torch.equal(z.detach(), zr.detach())                       # not rounded
+    zr.backward(gl)
+    assert torch.equal(a_s.grad, rd(ar.grad)) and torch.equal(m_s.grad, rd(mr.grad))
+    # an exception inside the block restores the stock functions too
+    with pytest.raises(RuntimeError):
+        with lowp.storage(dtype):
+            raise RuntimeError("x")
+    assert F.conv2d is stock_conv and F.linear is stock_lin
