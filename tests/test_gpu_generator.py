@@ -186,9 +186,10 @@ def test_inference_affine_cache_follows_training_steps(dev):
     stale = bn.running_mean._dsr_affine
     assert stale is not None
     g.train()
-    # a large learning rate so that three steps move gamma / beta far enough to tell stale maps from fresh ones
-    opt = optim.FusedAdam(g.parameters(), lr=2e-2)
-    st = recipes.GenOnlyState({k: v.clone() for k, v in sd.items()}, lr=2e-2)
+    # (three train-mode steps move the running statistics 27 % of the way to the batch statistics: at lr 1e-3 the oracle's
+    #  eval output moves by up to 0.88 -- far outside the 0.06 comparison bar below)
+    opt = optim.FusedAdam(g.parameters(), lr=1e-3)
+    st = recipes.GenOnlyState({k: v.clone() for k, v in sd.items()}, lr=1e-3)
     for _ in range(3):
         steps.gen_l1_step(g, opt, lr.to(dev), hr.to(dev))
         recipes.gen_l1_step(st, lr, hr)
@@ -199,7 +200,7 @@ def test_inference_affine_cache_follows_training_steps(dev):
     assert bn.running_mean._dsr_affine[0] != stale[0]                 # the key moved with the raw-pointer rewrites
     yr = gan.generator_forward(st.g, x, False)
     yr0 = gan.generator_forward(sd, x, False)
-    assert (yr - yr0).abs().max().item() > 0.2                         # the three steps changed the network's output a lot
+    assert (yr - yr0).abs().max().item() > 0.5                         # the three steps changed the network's output a lot
     assert (y1.cpu() - yr).abs().max().item() <= 0.06, (y1.cpu() - yr).abs().max().item()
     assert (y0.cpu() - yr0).abs().max().item() <= 0.06
 

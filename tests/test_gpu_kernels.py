@@ -559,17 +559,24 @@ def test_padded_coordinate_dma_path_equals_generic_loader(dev, pmode, stride):
     assert (got - ref).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("op", ["fwd", "fwd_stats", "dgrad", "dgrad_s2"])
+@pytest.mark.parametrize("op", ["fwd", "fwd_stats", "dgrad", "dgrad_masked", "dgrad_s2"])
 def test_conv_256x256_tile_equals_128x128(dev, op):
-    """The 256x256-tile variant of the gather kernel (8 waves of 128x64, one block per CU; conv_gemm.hip) walks K in the
-    same order as the 128x128 one, so it must reproduce it BIT FOR BIT; DSR_CONV_BIG=0 selects the 128x128 tile."""
+    """The 256x256-tile forms of the gather kernel (8 waves of 128x64, one block per CU; conv_gemm.hip) at a shape that
+    dispatches to them (314 tiles), three ways:
+      * one tile per block (DSR_CONV_STREAMK=0) walks K in the same order as the 128x128 tile (DSR_CONV_BIG=0): BIT FOR BIT;
+      * the stream-K form (default once a workspace is attached to the stream; 314 tiles on 256 CUs = tiles cut into two or
+        three pieces) sums a tile's K range in pieces: equal to the others within fp32 summation order (one bf16 ulp where
+        a sum lands next to a rounding boundary);
+      * ALL of them against a plain fp32 PyTorch reference of the same op on the same bf16 operands (conv2d /
+        conv_transpose2d on the CPU; BatchNorm sums of the REFERENCE's output), which is what ties the dominant kernel of the
+        batch-32 step to something other than another kernel of this library."""
     import ctypes as C
     import os
-    L = P("_lib")
+    L, Fm = P("_lib"), P("functional")
     lib = L.lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     n, h, w, cin, cout, stride = (3, 160, 167, 128, 256, 1) if op != "dgrad_s2" else (3, 320, 334, 256, 64, 2)
-    if op == "dgrad":
+    if op in ("dgrad", "dgrad_masked"):
         cin, cout = 256, 128
     d = L.ConvDesc(L.BF16, n, h, w, cin, cout, 3, 3, stride, 1, 0)
     oh, ow = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
@@ -581,13 +588,15 @@ def test_conv_256x256_tile_equals_128x128(dev, op):
     x = (torch.rand(n, h, w, cin, generator=g) - 0.5).to(torch.bfloat16).to(dev)
     dy = (torch.rand(n, oh, ow, cout, generator=g) - 0.5).to(torch.bfloat16).to(dev)
     bias = (torch.rand(cout, generator=g) - 0.5).to(dev)
-    outs, stats = [], []
-    old = os.environ.get("DSR_CONV_BIG")
-    old_s2 = os.environ.get("DSR_DGRAD_S2")
+    Fm._sk_attach()                         # the stream-K workspace of this stream (functional does this before its own launches)
+    assert Fm._sk_buffers[(torch.cuda.current_stream().device.index, torch.cuda.current_stream().cuda_stream)] is not None
+    outs, stats = {}, {}
+    keys = ("DSR_CONV_BIG", "DSR_DGRAD_S2", "DSR_CONV_STREAMK")
+    old = {k: os.environ.get(k) for k in keys}
     os.environ["DSR_DGRAD_S2"] = "0"       # this test is about the gather kernel's tiles: keep stride-2 dgrads on it
     try:
-        for mode in ("0", "2"):
-            os.environ["DSR_CONV_BIG"] = mode
+        for mode, big, sk, want in (("t128", "0", "0", "128x128"), ("t256", "2", "0", "256x256"), ("sk", "2", "1", "conv_gemm_sk")):
+            os.environ["DSR_CONV_BIG"], os.environ["DSR_CONV_STREAMK"] = big, sk
             if op in ("fwd", "fwd_stats"):
                 y = torch.full((n, oh, ow, cout), float("nan"), dtype=torch.bfloat16, device=dev)
                 rows = lib.dsr_conv_stats_rows(C.byref(d))
@@ -596,51 +605,57 @@ def test_conv_256x256_tile_equals_128x128(dev, op):
                                 part.data_ptr() if op == "fwd_stats" else None, 0, None)
                 name = lib.dsr_conv_kernel_name(C.byref(d), 0, C.byref(ep)).decode()
                 L.check(lib.dsr_conv_fwd(C.byref(d), x.data_ptr(), wf.data_ptr(), C.byref(ep), y.data_ptr(), st))
-                outs.append(y)
+                outs[mode] = y
                 if op == "fwd_stats":     # BatchNorm statistics: per-channel sum and sum of squares over all pixels
-                    stats.append(part[:rows * 2 * cout].reshape(rows, 2, cout).double().sum(0))
+                    stats[mode] = part[:rows * 2 * cout].reshape(rows, 2, cout).double().sum(0)
             else:
                 dx = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
-                wsz = lib.dsr_conv_dgrad_workspace(C.byref(d))
-                ws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=dev)
                 name = lib.dsr_conv_kernel_name(C.byref(d), 1, None).decode()
-                L.check(lib.dsr_conv_dgrad(C.byref(d), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), ws.data_ptr(), wsz, st))
-                outs.append(dx)
-            assert ("256x256" in name) == (mode == "2"), (mode, name)
+                if op == "dgrad_masked":       # dx * relu'(x): the activation mask folded into the store loop
+                    L.check(lib.dsr_conv_dgrad_masked(C.byref(d), dy.data_ptr(), wd.data_ptr(), x.data_ptr(), L.ACT_RELU, 0.0,
+                                                      dx.data_ptr(), st))
+                else:
+                    wsz = lib.dsr_conv_dgrad_workspace(C.byref(d))
+                    ws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=dev)
+                    L.check(lib.dsr_conv_dgrad(C.byref(d), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), ws.data_ptr(), wsz, st))
+                outs[mode] = dx
+            assert want in name, (mode, name)
+            # the stream-K launch leaves its flags clean (every published partial was consumed): the next launch depends on it
+            torch.cuda.synchronize()
+            buf = Fm._sk_buffers[(torch.cuda.current_stream().device.index, torch.cuda.current_stream().cuda_stream)]
+            assert int(buf[:4096].view(torch.int32).abs().sum()) == 0, mode
     finally:
-        for k, v in (("DSR_CONV_BIG", old), ("DSR_DGRAD_S2", old_s2)):
+        for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
     torch.cuda.synchronize()
-    assert torch.isfinite(outs[0].float()).all()
-    if os.environ.get("DSR_CONV_STREAMK", "1") == "0" or op == "dgrad_s2":
-        assert torch.equal(outs[0], outs[1])
-    else:
-        # a launch whose tiles do not fill whole rounds of the chip runs the 256x256 tile as stream-K pieces: the K range of a
-        # tile is then summed in two or more fp32 pieces, so the last bit of an accumulator may differ from the 128x128 tile's
-        assert rel_err(outs[1].float(), outs[0].float()) <= 2.0 ** -7
-    # ---- and against a plain fp32 PyTorch reference of the same op on the same bf16 operands, at THIS shape (the one that
-    # dispatches to the 256x256 tile): one bf16 rounding of the output = 2^-9 relative to the value, stated relative to the
-    # tensor's maximum as everywhere in this file
+    assert all(torch.isfinite(o.float()).all() for o in outs.values())
+    assert torch.equal(outs["t128"], outs["t256"])
+    assert rel_err(outs["sk"].float(), outs["t128"].float()) <= 2.0 ** -7
+    assert float((outs["sk"].float() != outs["t128"].float()).float().mean()) < 0.02      # and only a few elements differ at all
+    # ---- against a plain fp32 PyTorch reference of the same op on the same bf16 operands, at THIS shape: one bf16 rounding
+    # of the output = 2^-9 relative to the value, stated relative to the tensor's maximum as everywhere in this file
     xr, wr, dyr = x.float().cpu().permute(0, 3, 1, 2), wt.to(torch.bfloat16).float().cpu(), dy.float().cpu().permute(0, 3, 1, 2)
     if op in ("fwd", "fwd_stats"):
         pre = TF.conv2d(xr, wr, bias.cpu(), stride=stride, padding=1)
         ref = torch.relu(pre) if op == "fwd" else pre
     else:
         ref = TF.conv_transpose2d(dyr, wr, stride=stride, padding=1, output_padding=(h + 2 - 3) % stride if stride > 1 else 0)
-    for o in outs:
+        if op == "dgrad_masked":
+            ref = ref * (xr > 0).float()
+    for mode, o in outs.items():
         got = o.float().cpu().permute(0, 3, 1, 2)
         assert got.shape == ref.shape
-        assert rel_err(got, ref) <= 1.2e-2
-    if stats:    # same fp32 accumulators, summed in a different order (channel-major vs pixel-major epilogue)
-        assert torch.isfinite(stats[0]).all()
-        assert float((stats[0] - stats[1]).abs().max() / stats[0].abs().max()) < 1e-5
+        assert rel_err(got, ref) <= 1.2e-2, mode
+    if stats:    # same fp32 accumulators, summed in a different order (channel-major vs pixel-major epilogue, stream-K pieces)
+        assert all(torch.isfinite(s_).all() for s_ in stats.values())
+        assert float((stats["t128"] - stats["t256"]).abs().max() / stats["t128"].abs().max()) < 1e-5
         # per-channel sum / sum of squares of the REFERENCE's pre-activation output (fp32 conv on the CPU), not of the kernel's own
         ref_st = torch.stack([pre.double().sum((0, 2, 3)), (pre.double() ** 2).sum((0, 2, 3))])
-        for s in stats:
-            assert float((s.cpu() - ref_st).abs().max() / ref_st.abs().max()) < 1e-4
+        for mode, s_ in stats.items():
+            assert float((s_.cpu() - ref_st).abs().max() / ref_st.abs().max()) < 1e-4, mode
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 64, 96, 64, 64), (1, 50, 38, 128, 192), (3, 32, 32, 256, 64)])
