@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libdsr_hip.so")
 
-ABI_VERSION = 6          # bumped whenever a signature in include/dsr_hip.h changes; checked against the loaded library
+ABI_VERSION = 5          # bumped whenever a signature in include/dsr_hip.h changes; checked against the loaded library
 BF16, F16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_PRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_ELU = range(7)
 PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = range(3)
@@ -42,8 +42,6 @@ SIGNATURES = {
     "dsr_conv_wgrad_batched_workspace": (_Z, [_I, _DESC, C.POINTER(C.c_void_p)]),
     "dsr_conv_wgrad_batched": (_I, [_I, _DESC, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, _Z, _P]),
     "dsr_conv_kernel_name": (C.c_char_p, [_DESC, _I, C.POINTER(Epilogue)]),
-    "dsr_conv_streamk_bytes": (C.c_size_t, []),
-    "dsr_conv_streamk_attach": (_I, [_P, _P, C.c_size_t]),
     "dsr_clock_sample": (_I, [_P, _P]),
     "dsr_resample_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "dsr_noise_gaussian_u8": (_I, [_P, _P, _I, _P, _Z, _P]),
@@ -121,7 +119,7 @@ _lib = None
 # bench.py's roofline leg: a list here makes every launching entry point record (name, start_event, end_event) on the
 # stream it launches on (torch's current stream), so that the GPU-busy share of a step can be told from launch gaps.
 LAUNCH_LOG = None
-_NO_LAUNCH = ("dsr_last_error", "dsr_abi_version", "dsr_conv_kernel_name", "dsr_conv_streamk_bytes", "dsr_conv_streamk_attach", "dsr_conv_wgrad_batchable", "dsr_conv_wgrad_batched_workspace", "dsr_conv_dgrad_add_supported", "dsr_conv_dgrad_masked_supported", "dsr_conv_fwd_affine_supported",
+_NO_LAUNCH = ("dsr_last_error", "dsr_abi_version", "dsr_conv_kernel_name", "dsr_conv_wgrad_batchable", "dsr_conv_wgrad_batched_workspace", "dsr_conv_dgrad_add_supported", "dsr_conv_dgrad_masked_supported", "dsr_conv_fwd_affine_supported",
               "dsr_conv_first_bwd_supported", "dsr_conv_first_bwd_workspace", "dsr_conv_out_size", "dsr_conv_stats_rows",
               "dsr_conv_packed_elems", "dsr_conv_dgrad_workspace", "dsr_conv_wgrad_workspace", "dsr_pw_scratch_rows",
               "dsr_pw_reduce_blocks", "dsr_linear_fwd_workspace", "dsr_ssim_blocks")

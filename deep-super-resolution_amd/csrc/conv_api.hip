@@ -26,78 +26,7 @@ int dsr_launch_status(const char* what) {
   return DSR_OK;
 }
 extern "C" const char* dsr_last_error(void) { return g_err; }
-extern "C" int dsr_abi_version(void) { return 6; }
-
-// ---- stream-K workspace registry: the caller attaches one zero-initialised buffer per stream it launches convolutions on
-// (include/dsr_hip.h); the library only remembers the pointers.  Guarded by a mutex: launches may come from two threads.
-#include <mutex>
-namespace {
-struct SkEntry {
-  hipStream_t st;
-  void* ws;
-  size_t bytes;
-};
-std::mutex g_sk_mutex;
-SkEntry g_sk[32];
-int g_sk_count = 0;
-}   // namespace
-bool dsr_sk_lookup(hipStream_t st, void** ws, size_t* bytes) {
-  std::lock_guard<std::mutex> lock(g_sk_mutex);
-  for (int i = 0; i < g_sk_count; ++i)
-    if (g_sk[i].st == st) {
-      *ws = g_sk[i].ws;
-      *bytes = g_sk[i].bytes;
-      return g_sk[i].ws != nullptr;
-    }
-  return false;
-}
-bool dsr_sk_any_attached(void) {
-  std::lock_guard<std::mutex> lock(g_sk_mutex);
-  for (int i = 0; i < g_sk_count; ++i)
-    if (g_sk[i].ws) return true;
-  return false;
-}
-int dsr_sk_blocks(void) {
-  static int cached[64];
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  dev &= 63;
-  if (!cached[dev]) {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
-      (void)hipGetLastError();
-      cus = 0;
-    }
-    cus &= ~7;
-    cached[dev] = cus > DSR_SK_MAX_BLOCKS ? DSR_SK_MAX_BLOCKS : (cus > 0 ? cus : -1);
-  }
-  return cached[dev] > 0 ? cached[dev] : 0;
-}
-extern "C" size_t dsr_conv_streamk_bytes(void) {
-  const int blocks = dsr_sk_blocks();
-  return blocks > 0 ? (size_t)DSR_SK_FLAG_BYTES + (size_t)blocks * DSR_SK_SLOT_BYTES : 0;
-}
-extern "C" int dsr_conv_streamk_attach(dsr_stream_t s, void* workspace, size_t bytes) {
-  if (workspace && bytes < dsr_conv_streamk_bytes())
-    return dsr_fail(DSR_E_WORKSPACE, "conv_streamk_attach: %zu bytes < %zu", bytes, dsr_conv_streamk_bytes());
-  if (workspace && ((size_t)workspace & 15)) return dsr_fail(DSR_E_ARG, "conv_streamk_attach: workspace must be 16-byte aligned");
-  std::lock_guard<std::mutex> lock(g_sk_mutex);
-  for (int i = 0; i < g_sk_count; ++i)
-    if (g_sk[i].st == s) {
-      g_sk[i].ws = workspace;       // (null detaches)
-      g_sk[i].bytes = bytes;
-      return DSR_OK;
-    }
-  if (!workspace) return DSR_OK;
-  for (int i = 0; i < g_sk_count; ++i)
-    if (!g_sk[i].ws) {              // reuse a detached entry
-      g_sk[i] = SkEntry{s, workspace, bytes};
-      return DSR_OK;
-    }
-  if (g_sk_count == 32) return dsr_fail(DSR_E_UNSUPPORTED, "conv_streamk_attach: more than 32 streams");
-  g_sk[g_sk_count++] = SkEntry{s, workspace, bytes};
-  return DSR_OK;
-}
+extern "C" int dsr_abi_version(void) { return 5; }
 
 static inline int r8(int c) { return (c + 7) & ~7; }
 
@@ -792,10 +721,8 @@ extern "C" int dsr_conv_wgrad_batched(int count, const dsr_conv_desc* descs, con
 }
 
 // ---- measurement aid: the kernel family the dispatch above selects (kept next to it so the two cannot drift far)
-static const char* gemm_name(int nb, long long M = 0, bool fast = false, bool stats = true, int ksteps = 0, int flags = 0) {
-  // (stream-K needs a workspace attached to the launch stream; this aid has no stream and answers for "some stream has one")
-  if (nb > 64 && ksteps > 0 && dsr_sk_any_attached() && dsr_conv_gemm_use_sk(M, nb, ksteps, fast, flags, dsr_sk_blocks()))
-    return "conv_gemm_sk_kernel";
+static const char* gemm_name(int nb, long long M = 0, bool fast = false, bool stats = true, int flags = 0) {
+  if (nb > 64 && dsr_conv_gemm_use_224(M, nb, fast, flags | (stats ? DSR_F_STATS : 0))) return "conv_gemm_kernel<224x256>";
   if (nb > 64 && dsr_conv_gemm_use_256(M, nb, fast, stats)) return "conv_gemm_kernel<256x256>";
   return nb > 64 ? "conv_gemm_kernel<128x128>" : (nb > 16 ? "conv_gemm_kernel<128x64>" : "conv_gemm_kernel<128x16>");
 }
@@ -813,7 +740,7 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
     int OH, OW;
     dsr_conv_out_size(d, &OH, &OW);
     return gemm_name(r8(d->Cout), (long long)d->N * OH * OW, d->pad_mode == DSR_PAD_ZERO && r8(d->Cin) % 64 == 0, stats,
-                     d->KH * d->KW * (r8(d->Cin) / 64), (ps ? DSR_F_PIXSHUF : 0) | (nchw ? DSR_F_OUT_NCHW_F32 : 0));
+                     (ps ? DSR_F_PIXSHUF : 0) | (nchw ? DSR_F_OUT_NCHW_F32 : 0));
   }
   if (op == 1) {
     if (is_c64(d)) return "conv_c64_kernel<1>";
@@ -823,9 +750,7 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
       return "conv_dgrad_s2_kernel";
     // input gradient on the gather kernel: grid = the input pixels (stride 1) or one output-parity class of them (stride 2)
     const long long Mg = (long long)d->N * ((d->H + d->stride - 1) / d->stride) * ((d->W + d->stride - 1) / d->stride);
-    return gemm_name(r8(d->Cin), Mg, r8(d->Cout) % 64 == 0 && (d->pad_mode == DSR_PAD_ZERO || d->pad == 0), false,
-                     // (stride 2: the K loop of the output-parity class with the most taps)
-                     ((d->KH + d->stride - 1) / d->stride) * ((d->KW + d->stride - 1) / d->stride) * (r8(d->Cout) / 64), 0);
+    return gemm_name(r8(d->Cin), Mg, r8(d->Cout) % 64 == 0 && (d->pad_mode == DSR_PAD_ZERO || d->pad == 0), false);
   }
   WgradTileArgs t;
   bool taps = false;

@@ -22,11 +22,6 @@
 #include "dsr_common.h"
 #include "dsr_kernels.h"
 
-static bool env_on(const char* name) {   // tuning switches, default on ("0" turns one off)
-  const char* e = getenv(name);
-  return !(e && e[0] == '0');
-}
-
 template <int BM, int BN, int WGM, int NSTAGE>
 struct ConvGemmLds {
   static constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128;
@@ -40,7 +35,7 @@ struct ConvGemmLds {
 // pad = 'reflection'): the padded coordinate of every A row is recomputed per K-step (a dozen VALU instructions per piece)
 // instead of falling back to the register-staged generic loader -- 10.6 us against 23.6 us per 128 -> 128 layer at 128^2.
 template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA, int NSTAGE, bool SWAP, bool PADX = false>
-__global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 256 * 256) ? 2 : (WGM * WGN) / 2) void conv_gemm_kernel(const ConvGemmArgs a) {
+__global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 224 * 256) ? 2 : (WGM * WGN) / 2) void conv_gemm_kernel(const ConvGemmArgs a) {
   static_assert(!DMA || FAST, "the LDS-DMA loader exists for the fast path only");
   static_assert(!PADX || (DMA && NSTAGE == 2 && WGM * WGN == 4), "padded-coordinate form: 4-wave two-stage DMA kernels only");
   static_assert(NSTAGE == 2 || (NSTAGE == 3 && DMA), "three stages: DMA ring only");
@@ -51,8 +46,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 256 * 25
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 16, TN = WN / 16;
   static_assert(TM >= 1 && TN >= 1, "wave tile");
-  constexpr int RA = BM / RPP;
+  // (BM = 224: the 8-wave tile with 7 instead of 8 m-tiles per wave; its loader's last pass covers 32 rows only -- waves 4..7
+  //  sit it out, wave-uniformly: a DMA piece writes its 8 rows whatever the offsets are, and theirs lie behind the stage)
+  constexpr int RA = (BM + RPP - 1) / RPP;
   constexpr int RB = (BN + RPP - 1) / RPP;
+  static_assert(BM % RPP == 0 || (DMA && BM % 8 == 0), "partial loader pass: LDS-DMA variants only");
+  static_assert(BM % 128 == 0 || BM == 224, "tile heights");
   constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128;
   constexpr int LDS_MAIN = NSTAGE * (A_STAGE + B_STAGE);
   constexpr int C_STRIDE = BN * 2 + 16;
@@ -191,6 +190,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 256 * 25
     typedef __attribute__((address_space(3))) void* lds_ptr;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
+      if (RPP * (i + 1) > BM && wave * 8 + RPP * i >= BM) continue;   // (compile-time false for whole passes)
       unsigned off;
       if constexpr (PADX) {
         bool ok = a_ok[i];
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 256 * 25
   }
   __syncthreads();
 
-  if (do_stats) {
+  if (BM % 128 == 0 && do_stats) {       // (the 224-row tile is only launched without statistics)
     for (int c = tid; c < 2 * BN; c += NT) {
       int which = c / BN, ct = c % BN;
       int col = n0 + ct;
@@ -727,391 +727,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 256 * 25
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Stream-K form of the 256x256 tile (same 8 waves of 128x64, same LDS-DMA loader, same software-pipelined K-step, same
-// channel-major epilogue as conv_gemm_kernel<256,256,2,4,true,true,2,true>).  One block per CU, every block gets the same
-// number of K-steps (+-1) of the launch, walking the tiles in order; a tile is cut where a block's share ends.
-// Why: a 256x256 launch of 196 tiles (VGG 512 -> 512 at 28x28, batch 32) or 392 tiles (256 -> 256 at 56x56) leaves 23 % of
-// the chip idle in its last round when every block owns whole tiles.
-//   * The grid is dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), and each XCD's blocks share a contiguous
-//     range of tiles: a cut tile's pieces live on ONE XCD, on blocks with consecutive idx = blockIdx.x / 8.
-//   * A block's share is [tail of tile t][whole tiles][head of tile u].  The head (a piece that does not contain the tile's
-//     last K-step) is computed FIRST and published as an fp32 partial tile (write-through stores, then a flag); the tail's
-//     owner finishes the tile: it adds the partials of the blocks idx-1, idx-2, ... that hold the earlier pieces and runs the
-//     epilogue.  Its producers published at the START of their run, so it normally finds the flags set.
-//   * A consumer only ever waits for blocks with a LOWER idx on its own XCD, which the dispatcher started before it: the wait
-//     cannot deadlock, whatever else runs on the chip (a second stream's launch included).
-//   * Deterministic: the pieces of a tile are summed in a fixed order.  Not bit-identical to the one-tile-per-block kernel
-//     (the K range is summed in two or more fp32 pieces).  Flags are reset by their consumer: the workspace stays clean.
-template <int DT>
-__global__ __launch_bounds__(512, 2) void conv_gemm_sk_kernel(const ConvGemmArgs a) {
-  constexpr int BM = 256, BN = 256, WGM = 2, WGN = 4, NSTAGE = 2;
-  constexpr int NT = 512, RPP = 64, WM = 128, WN = 64, TM = 8, TN = 4, RA = 4, RB = 4;
-  constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128;
-  constexpr int C_STRIDE = BN * 2 + 16;
-  constexpr int LDS_BYTES = ConvGemmLds<BM, BN, WGM, NSTAGE>::TILE;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;
-  unsigned char* sB = smem + NSTAGE * A_STAGE;
-  float* sStat = reinterpret_cast<float*>(smem + LDS_BYTES);
-  int* sTaps = reinterpret_cast<int*>(smem + LDS_BYTES + WGM * 2 * BN * 4);
-  unsigned char* sC = smem;
-
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
-
-  // ---- this block's share of the launch
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-  const int T = a.tiles_m * a.tiles_n;
-  const int t_lo = (int)((long long)T * xcd / 8), t_hi = (int)((long long)T * (xcd + 1) / 8);
-  const int ks = a.ksteps;
-  const long long Wk = (long long)(t_hi - t_lo) * ks;            // K-steps of this XCD's tiles
-  const int w0 = (int)(Wk * idx / bpx), w1 = (int)(Wk * (idx + 1) / bpx);
-  if (w0 >= w1) return;                                          // (the dispatcher guarantees >= 2 K-steps per block)
-  const int t_first = w0 / ks, t_last = (w1 - 1) / ks;
-  const int np = t_last - t_first + 1;
-  const bool head_first = (w1 - t_last * ks) < ks && np > 1;     // the last piece is a head: compute and publish it first
-
-  for (int i = tid; i < a.ntaps; i += NT) sTaps[i] = a.taps[i];
-  __syncthreads();
-
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
-  constexpr unsigned OOB = 0xFFFFFFF0u;
-  const int cu8 = a.CU >> 3;
-  const float slope = (a.flags & DSR_F_PRELU_PTR) ? a.prelu[0] : a.slope;
-  const bool do_stats = (a.flags & DSR_F_STATS) != 0;
-  const unsigned my_slot = blockIdx.x;
-  float* const my_part = a.sk_part + (size_t)my_slot * (BM * BN);
-
-  struct TapStep {
-    int dy, dx, toff, woff;
-  };
-  auto decode_step = [&](int s) {
-    const int t = fd_div(a.fd_cu8, s);
-    const int cbase = (s - t * cu8) * 64;
-    const int tp = sTaps[t];
-    TapStep d;
-    d.dy = (int)(signed char)(tp & 0xff);
-    d.dx = (int)(signed char)((tp >> 8) & 0xff);
-    const int widx = (tp >> 16) & 0xffff;
-    d.toff = ((d.dy * a.IW + d.dx) * a.CinP + cbase) * 2;
-    d.woff = (widx * a.NB * a.CinP + cbase) * 2;
-    return d;
-  };
-
-  for (int pi = 0; pi < np; ++pi) {
-    // piece order: [head of the last tile] first when there is one, then the pieces in tile order
-    const int q = head_first ? (pi == 0 ? np - 1 : pi - 1) : pi;
-    const int tl = t_first + q;                                  // tile index inside this XCD's range
-    const int k0 = q == 0 ? w0 - t_first * ks : 0;
-    const int k1 = q == np - 1 ? w1 - tl * ks : ks;
-    const int tile = t_lo + tl;
-    const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    // every lane-derived value is re-derived per piece from an opaque copy of the thread id: the optimiser would otherwise
-    // hoist the invariant parts of the per-tile address arithmetic (and of the epilogue's) out of the piece loop and keep
-    // them in registers across the K loop, which has none to spare (it spilled four fragment addresses INTO the K loop)
-    int ptid = tid;
-    asm volatile("" : "+v"(ptid));
-    const int lane = ptid & 63;
-    const int g = lane >> 4, r16 = lane & 15;
-    const int j = ptid & 7, rb = ptid >> 3;
-    const int jc = j ^ (rb & 7);
-    const int sw = r16 & 7;
-
-    // ---- loader state of this tile: unit j of the K-step, rows rb + 64 i
-    int a_iy0[RA], a_ix0[RA], a_base[RA], b_base[RB];
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      const int m = m0 + rb + RPP * i;
-      const bool ok = m < a.M;
-      const int mm = ok ? m : 0;
-      const int n = fd_div(a.fd_ghw, mm);
-      const int rem = mm - n * (a.GH * a.GW);
-      const int gy = fd_div(a.fd_gw, rem);
-      const int gx = rem - gy * a.GW;
-      a_iy0[i] = ok ? gy * a.isy : -(1 << 20);                   // rows past M: every tap lands out of range
-      a_ix0[i] = gx * a.isx;
-      a_base[i] = ((n * a.IH * a.IW + a_iy0[i] * a.IW + a_ix0[i]) * a.CinP + jc * 8) * 2;
-    }
-#pragma unroll
-    for (int i = 0; i < RB; ++i) b_base[i] = ((n0 + rb + RPP * i) * a.CinP + jc * 8) * 2;   // NB % 256 == 0: every row exists
-    auto dma_issue = [&](const TapStep& d, int stage) {
-      typedef __attribute__((address_space(3))) void* lds_ptr;
-#pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        const bool inb = (unsigned)(a_iy0[i] + d.dy) < (unsigned)a.IH && (unsigned)(a_ix0[i] + d.dx) < (unsigned)a.IW;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(sA + stage * A_STAGE + (wave * 8 + RPP * i) * 128), 16,
-                                                 inb ? (unsigned)(a_base[i] + d.toff) : OOB, 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < RB; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + stage * B_STAGE + (wave * 8 + RPP * i) * 128), 16,
-                                                 (unsigned)(b_base[i] + d.woff), 0, 0, 0);
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int k = 0; k < TN; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- K-steps k0 .. k1-1 of this tile (the loop of conv_gemm_kernel's 256x256 instantiation, see the comments there)
-    {
-      const bool late_dma = wave >= 4;
-      dma_issue(decode_step(k0), 0);
-      TapStep nd = decode_step(k0 + 1 < k1 ? k0 + 1 : k0);
-      for (int s = k0; s < k1; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const int cur = (s - k0) & 1;
-        const unsigned char* pa = sA + cur * A_STAGE + (wm * WM + r16) * 128;
-        const unsigned char* pb = sB + cur * B_STAGE + (wn * WN + r16) * 128;
-        const int slot0 = (g ^ sw) << 4, slot1 = ((4 + g) ^ sw) << 4;
-        constexpr int NU = 2 * TM;
-        U4 fb0[TN], fb1[TN], fa[3];
-        auto a_frag = [&](int u) { return *reinterpret_cast<const U4*>(pa + (u % TM) * 16 * 128 + (u < TM ? slot0 : slot1)); };
-#pragma unroll
-        for (int k = 0; k < TN; ++k) fb0[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot0);
-        fa[0] = a_frag(0);
-        fa[1] = a_frag(1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!late_dma && s + 1 < k1) dma_issue(nd, cur ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-          if (u + 2 < NU) fa[(u + 2) % 3] = a_frag(u + 2);
-          if (u == TM - 3) {
-#pragma unroll
-            for (int k = 0; k < TN; ++k) fb1[k] = *reinterpret_cast<const U4*>(pb + k * 16 * 128 + slot1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int k = 0; k < TN; ++k) {
-            const U4& fbk = u < TM ? fb0[k] : fb1[k];
-            acc[u % TM][k] = mfma16<DT>(fbk, fa[u % 3], acc[u % TM][k]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (u == TM - 1) {
-            if (late_dma && s + 1 < k1) dma_issue(nd, cur ^ 1);
-            if (s + 2 < k1) nd = decode_step(s + 2);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-    }
-
-    if (k1 < ks) {
-      // ---- head / middle piece: publish the fp32 partial tile.  Write-through (sc1) 16-byte stores, lane-linear: every
-      // wave instruction writes one contiguous KB; then every wave drains its stores, a barrier, and one lane sets the flag.
-      {
-        int tv = tid;
-        asm volatile("" : "+v"(tv));       // (opaque: keeps the address arithmetic of this branch out of the K loop's registers)
-        const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(my_part, 0, DSR_SK_SLOT_BYTES, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int k = 0; k < TN; ++k)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, acc[i][k]), pr,
-                                                   (unsigned)tv * 16u, (i * TN + k) * NT * 16, 16 /* sc1: write-through */);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();      // (also: every wave is done with the LDS stages before the next piece's first DMA)
-      if (tid == 0) __hip_atomic_store(a.sk_flags + my_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      continue;
-    }
-    if (k0 > 0) {
-      // ---- tail piece: add the partial tiles of the blocks that hold this tile's earlier K-steps (idx-1 downwards, until
-      // the one whose share starts at or before the tile's first K-step)
-      for (int jj = idx - 1; jj >= 0; --jj) {
-        const int wj0 = (int)(Wk * jj / bpx);
-        const unsigned slot = ((unsigned)jj << 3) | (unsigned)xcd;
-        if (wave == 0) {
-          if (lane == 0) {
-            // (bounded: a wait that cannot end -- a corrupted workspace -- must not hang the GPU; ~2 s, then the last flag word
-            //  is set, the tile is finished from whatever the slot holds and the host side can see that it happened)
-            int spins = 0;
-            while (__hip_atomic_load(a.sk_flags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 21))
-              __builtin_amdgcn_s_sleep(4);
-            if (spins >= (1 << 21)) __hip_atomic_store(a.sk_flags + (DSR_SK_FLAG_BYTES / 4 - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.sk_flags + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: clean for the next launch
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-        const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(a.sk_part + (size_t)slot * (BM * BN), 0, DSR_SK_SLOT_BYTES, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          f32x4 v[TN];
-#pragma unroll
-          for (int k = 0; k < TN; ++k)
-            v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, (unsigned)tv * 16u, (i * TN + k) * NT * 16, 0));
-#pragma unroll
-          for (int k = 0; k < TN; ++k) acc[i][k] += v[k];
-        }
-        if (wj0 <= tl * ks) break;
-      }
-    }
-    __syncthreads();   // the epilogue reuses the stages as its C tile
-
-    // ---- epilogue (channel-major accumulators: acc[i][k][jj] = out[row wm*128 + 16 i + r16][col wn*64 + 16 k + 4 g + jj])
-    // (lane-derived values re-derived from an opaque copy of the thread id: the optimiser would otherwise hoist the epilogue's
-    //  per-lane address arithmetic out of the piece loop and keep it in registers across the K loop, which has none to spare)
-    int etid = tid;
-    asm volatile("" : "+v"(etid));
-    const int eg = (etid & 63) >> 4, er16 = etid & 15;
-    auto epilogue = [&](auto actf, auto stats_tag) {
-      constexpr bool ST = decltype(stats_tag)::value;
-      const int g = eg, r16 = er16;
-#pragma unroll
-      for (int k = 0; k < TN; ++k) {
-        const int ct0 = wn * WN + 16 * k + 4 * g;
-        float bv[4], s1[4], s2[4];
-        bool cok[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int col = n0 + ct0 + jj;
-          cok[jj] = col < a.cout;
-          bv[jj] = ((a.flags & DSR_F_BIAS) && cok[jj]) ? a.bias[col] : 0.f;
-          s1[jj] = s2[jj] = 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int row = wm * WM + 16 * i + r16;
-          const bool rok = m0 + row < a.M;
-          float o[4];
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const float v = acc[i][k][jj] + bv[jj];
-            if constexpr (ST) {
-              const float vm = (rok && cok[jj]) ? v : 0.f;
-              s1[jj] += vm;
-              s2[jj] = __builtin_fmaf(vm, vm, s2[jj]);
-            }
-            o[jj] = cok[jj] ? actf(v) : 0.f;
-          }
-          uint2 h;
-          h.x = (unsigned)f2h<DT>(o[0]) | ((unsigned)f2h<DT>(o[1]) << 16);
-          h.y = (unsigned)f2h<DT>(o[2]) | ((unsigned)f2h<DT>(o[3]) << 16);
-          *reinterpret_cast<uint2*>(sC + row * C_STRIDE + ct0 * 2) = h;
-        }
-        if constexpr (ST) {
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-#pragma unroll
-            for (int x = 1; x < 16; x <<= 1) {
-              s1[jj] += __shfl_xor(s1[jj], x, 64);
-              s2[jj] += __shfl_xor(s2[jj], x, 64);
-            }
-          }
-          if (r16 == 0) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              sStat[(wm * 2 + 0) * BN + ct0 + jj] = s1[jj];
-              sStat[(wm * 2 + 1) * BN + ct0 + jj] = s2[jj];
-            }
-          }
-        }
-      }
-    };
-    auto run_epilogue = [&](auto actf) {
-      if (do_stats)
-        epilogue(actf, std::true_type{});
-      else
-        epilogue(actf, std::false_type{});
-    };
-    if (a.act == DSR_ACT_NONE)
-      run_epilogue([](float v) { return v; });
-    else if (a.act == DSR_ACT_RELU)
-      run_epilogue([](float v) { return v > 0.f ? v : 0.f; });
-    else if (a.act == DSR_ACT_LEAKY || a.act == DSR_ACT_PRELU)
-      run_epilogue([slope](float v) { return v >= 0.f ? v : v * slope; });
-    else
-      run_epilogue([&](float v) { return act_apply(a.act, v, slope); });
-    __syncthreads();
-
-    if (do_stats) {
-      for (int c = etid; c < 2 * BN; c += NT) {
-        const int which = c / BN, ct = c % BN;
-        const int col = n0 + ct;
-        if (col < a.cout) {
-          // one statistics row per 128 tile rows (dsr_conv_stats_rows): wave row wm IS that row here
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-            if (m0 + 128 * h < a.M) a.stats[((size_t)(tile_m * 2 + h) * 2 + which) * a.stats_stride + col] = sStat[(h * 2 + which) * BN + ct];
-        }
-      }
-    }
-    unsigned short* __restrict__ Y = reinterpret_cast<unsigned short*>(a.y);
-    constexpr int CH = BN / 8;
-    if (a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.GH == a.OH && a.GW == a.OW && m0 + BM <= a.M &&
-        n0 + BN <= a.CoutP && (size_t)a.M * a.CoutP * 2 < 0xFFFFFF00ull) {
-      // dense output, tile fully inside the matrix: one scalar per tile, a per-lane constant and a scalar step per pass
-      const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)((size_t)a.M * a.CoutP * 2), 0x00020000);
-      const unsigned sorg = (unsigned)(((size_t)m0 * a.CoutP + n0) * 2);
-      const unsigned lpart = (unsigned)((etid / CH) * a.CoutP * 2 + (etid % CH) * 16);
-      const unsigned step = (unsigned)((NT / CH) * a.CoutP * 2);
-      const unsigned char* src = sC + (etid / CH) * C_STRIDE + (etid % CH) * 16;
-      if (a.mask_x) {       // (uniform) dgrad with the upstream activation's backward mask folded into the stores
-        const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.mask_x), 0, (unsigned)((size_t)a.M * a.CoutP * 2), 0x00020000);
-#pragma unroll
-        for (int it = 0; it < (BM * CH) / NT; ++it) {
-          const U4 v = *reinterpret_cast<const U4*>(src + it * (NT / CH) * C_STRIDE);
-          const U4 o = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(mr, sorg + lpart + it * step, 0, 0));
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned,
-                                                                    act_mask8<DT>(v, o, a.mask_act, a.mask_slope)),
-                                                 yr, sorg + lpart + it * step, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int it = 0; it < (BM * CH) / NT; ++it) {
-          const U4 v = *reinterpret_cast<const U4*>(src + it * (NT / CH) * C_STRIDE);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), yr,
-                                                 sorg + lpart + it * step, 0, 0);
-        }
-      }
-    } else {
-      for (int ix = etid; ix < BM * CH; ix += NT) {
-        const int row = ix / CH, ch = ix % CH;
-        const int m = m0 + row, col0 = n0 + ch * 8;
-        if (m < a.M && col0 < a.CoutP) {
-          const int n = fd_div(a.fd_ghw, m);
-          const int rem = m - n * (a.GH * a.GW);
-          const int gy = fd_div(a.fd_gw, rem);
-          const int gx = rem - gy * a.GW;
-          const int oy = gy * a.osy + a.ooy, ox = gx * a.osx + a.oox;
-          const size_t off = ((size_t)(n * a.OH + oy) * a.OW + ox) * a.CoutP + col0;
-          U4 v = *reinterpret_cast<const U4*>(sC + row * C_STRIDE + ch * 16);
-          if (a.mask_x)
-            v = act_mask8<DT>(v, *reinterpret_cast<const U4*>(reinterpret_cast<const unsigned short*>(a.mask_x) + off), a.mask_act, a.mask_slope);
-          *reinterpret_cast<U4*>(Y + off) = v;
-        }
-      }
-    }
-    __syncthreads();   // the C tile has been read: the next piece's first DMA may overwrite the stages
-  }
-}
-
-template <int DT>
-static void launch_sk(const ConvGemmArgs& a, void* ws, int blocks, hipStream_t st) {
-  constexpr int LDS = ConvGemmLds<256, 256, 2, 2>::TOTAL;
-  ConvGemmArgs b = a;
-  b.tiles_m = (a.M + 255) / 256;
-  b.tiles_n = a.NB / 256;
-  b.sk_flags = reinterpret_cast<unsigned*>(ws);
-  b.sk_part = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + DSR_SK_FLAG_BYTES);
-  auto* fn = conv_gemm_sk_kernel<DT>;
-  static LdsOptIn optin;
-  optin.ensure((const void*)fn, LDS);
-  hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), LDS, st, b);
-}
-
 template <int DT, int BM, int BN, int WGM, int WGN, bool FAST, bool DMA, int NSTAGE, bool SWAP, bool PADX = false>
 static void launch_swap(dim3 grid, const ConvGemmArgs& b, hipStream_t st) {
   constexpr int LDS = ConvGemmLds<BM, BN, WGM, NSTAGE>::TOTAL;
@@ -1130,15 +745,19 @@ static void launch_variant(dim3 grid, const ConvGemmArgs& b, hipStream_t st) {
   if constexpr (DMA) {
     // (the 256x256 tile has no register room for the pixel-major epilogue: it takes its statistics from the
     //  channel-major accumulators -- 16-lane shuffle sums -- as well)
-    if (!(b.flags & DSR_F_STATS) || BM >= 256) {
+    if (!(b.flags & DSR_F_STATS) || BM >= 224) {
       launch_swap<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE, true, PADX>(grid, b, st);
       return;
     }
   }
   // statistics launches, and the register-staged variants (measured 10 % slower with the channel-major epilogue)
-  if constexpr (BM < 256) launch_swap<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE, false, PADX>(grid, b, st);
+  if constexpr (BM < 224) launch_swap<DT, BM, BN, WGM, WGN, FAST, DMA, NSTAGE, false, PADX>(grid, b, st);
 }
 
+static bool env_on(const char* name) {   // tuning switches, default on ("0" turns one off)
+  const char* e = getenv(name);
+  return !(e && e[0] == '0');
+}
 
 template <int DT, int BM, int BN, int WGM, int WGN, int NSTAGE = 2>
 static void launch_one(const ConvGemmArgs& a, hipStream_t st) {
@@ -1165,7 +784,7 @@ static void launch_one(const ConvGemmArgs& a, hipStream_t st) {
         }
       }
     }
-    if constexpr (BM < 256) {       // (the 256x256 tile exists as the LDS-DMA fast path only; dispatch_dt guarantees it)
+    if constexpr (BM < 224) {       // (the 8-wave tiles exist as the LDS-DMA fast path only; dispatch_dt guarantees it)
       if (fast)
         launch_variant<DT, BM, BN, WGM, WGN, true, false, 2>(grid, b, st);
       else
@@ -1185,7 +804,9 @@ static void dispatch_dt(const ConvGemmArgs& a, hipStream_t st) {
     // 256x256 tile, 8 waves of 128x64 (2 x 4), two stages, one block per CU: per MFMA half the LDS fragment reads
     // (0.375 ds_read_b128 per MFMA instead of 0.5) and half the DMA pieces of the 128x128 tile
     const int big_mode = dsr_conv_big_mode();
-    if (dsr_conv_gemm_use_256(a.M, a.NB, fast && env_on("DSR_CONV_DMA"), (a.flags & DSR_F_STATS) != 0))
+    if (dsr_conv_gemm_use_224(a.M, a.NB, fast && env_on("DSR_CONV_DMA"), a.flags))
+      launch_one<DT, 224, 256, 2, 4>(a, st);
+    else if (dsr_conv_gemm_use_256(a.M, a.NB, fast && env_on("DSR_CONV_DMA"), (a.flags & DSR_F_STATS) != 0))
       launch_one<DT, 256, 256, 2, 4>(a, st);
     else if (use_big && big_mode == 1 && fast && big_tiles >= 512)
       launch_one<DT, 256, 128, 4, 2, 3>(a, st);
@@ -1200,24 +821,6 @@ static void dispatch_dt(const ConvGemmArgs& a, hipStream_t st) {
 void dsr_launch_conv_gemm(const ConvGemmArgs& a, int dtype, hipStream_t st) {
   if (!a.mask_x) {          // (the persistent kernels keep a DMA in flight across their epilogue: no masked form)
     if (dsr_launch_conv_gemm_persist(a, dtype, st)) return;   // many-tile fast-path launches: persistent kernel
-  }
-  {
-    // 256x256 tiles that do not fill whole rounds of the chip: stream-K pieces, when the caller attached a workspace to this
-    // stream (dsr_conv_streamk_attach)
-    void* ws = nullptr;
-    size_t wsb = 0;
-    const bool fast = a.pad_mode == DSR_PAD_ZERO && (a.CU & 7) == 0 && a.ntaps > 0 && env_on("DSR_CONV_DMA");
-    if (a.NB > 64 && dsr_sk_lookup(st, &ws, &wsb)) {
-      const int blocks = dsr_sk_blocks();
-      if (dsr_conv_gemm_use_sk(a.M, a.NB, a.ksteps, fast, a.flags, blocks) &&
-          wsb >= (size_t)DSR_SK_FLAG_BYTES + (size_t)blocks * DSR_SK_SLOT_BYTES && (size_t)a.M * a.CoutP * 2 < 0xFFFFFF00ull) {
-        if (dtype == DSR_DTYPE_BF16)
-          launch_sk<DSR_DTYPE_BF16>(a, ws, blocks, st);
-        else
-          launch_sk<DSR_DTYPE_F16>(a, ws, blocks, st);
-        return;
-      }
-    }
   }
   if (dtype == DSR_DTYPE_BF16)
     dispatch_dt<DSR_DTYPE_BF16>(a, st);

@@ -63,10 +63,6 @@ struct ConvGemmArgs {
   const void* mask_x;
   int mask_act;
   float mask_slope;
-  // stream-K form of the 256x256 tile (conv_gemm_sk_kernel): per-block fp32 partial-tile slots and their ready flags, both in
-  // the workspace the caller attached to the launch stream (dsr_conv_streamk_attach)
-  float* sk_part;
-  unsigned* sk_flags;
   int taps[DSR_MAX_TAPS];   // (dy & 0xff) | (dx & 0xff) << 8 | widx << 16
 };
 
@@ -85,27 +81,21 @@ static inline bool dsr_conv_gemm_use_256(long long M, int NB, bool fast, bool st
   return dsr_conv_big_mode() == 2 && fast && NB % 256 == 0 && tiles >= (t ? atoi(t) : 150);
 }
 
-// ---- stream-K workspace registry (conv_api.hip): one caller-owned buffer per stream, [flags: DSR_SK_FLAG_BYTES, zero when
-// attached and kept zero by the kernel][one 256 KB fp32 partial-tile slot per block]
-#define DSR_SK_FLAG_BYTES 4096
-#define DSR_SK_SLOT_BYTES (256 * 256 * 4)
-#define DSR_SK_MAX_BLOCKS 512
-bool dsr_sk_lookup(hipStream_t st, void** ws, size_t* bytes);
-bool dsr_sk_any_attached(void);
-int dsr_sk_blocks(void);      // blocks of a stream-K launch on the current device: one per CU, a multiple of 8
-// A 256x256-tile launch whose tiles do not fill whole rounds of the chip runs as stream-K pieces: every block gets the same
-// number of K-steps (+-1), tiles are cut where a block's share ends, partial tiles are summed by the block that finishes them.
-// DSR_CONV_STREAMK=0 turns it off (read per call: tests compare the forms).
-static inline bool dsr_conv_gemm_use_sk(long long M, int NB, int ksteps, bool fast, int flags, int blocks) {
-  const char* e = getenv("DSR_CONV_STREAMK");
-  if ((e && e[0] == '0') || !fast || NB % 256 != 0 || blocks < 8) return false;
-  if (flags & (DSR_F_PIXSHUF | DSR_F_OUT_NCHW_F32)) return false;
-  const long long tiles = ((M + 255) / 256) * (NB / 256);
-  const char* mt = getenv("DSR_CONV_STREAMK_MIN_TILES");   // tuning switch
-  if (tiles < (mt ? atoi(mt) : 40) || dsr_conv_big_mode() != 2) return false;
-  if ((tiles / 8) * (long long)ksteps < 2ll * (blocks / 8)) return false;         // every block gets at least two K-steps
-  const long long rounds = (tiles + blocks - 1) / blocks;
-  return tiles * 10 < rounds * blocks * 9;                // less than 90 % of the slots of its last round filled
+// 224x256 tile (the same 8-wave kernel with 7 m-tiles per wave): a launch whose 256-row tiles leave most of the chip idle in
+// their last round -- VGG19 at batch 32: 196 tiles (512 channels at 28x28) or 392 tiles (256 channels at 56x56) on the 256
+// CUs of an MI355X, i.e. 77 % of the slots of one / two rounds -- runs 224 / 448 tiles of 7/8 the work each instead: the same
+// number of rounds, every round 12.5 % shorter.  Taken when it lowers rounds x rows per tile, for launches without BatchNorm
+// statistics (one statistics row per 128 tile rows has no place in a 224-row tile) and without PixelShuffle stores.
+// DSR_CONV_BM224: 0 = never, 1 (default) = by that cost, 2 = wherever the 256x256 tile would be taken (tests).
+static inline bool dsr_conv_gemm_use_224(long long M, int NB, bool fast, int flags) {
+  const char* e = getenv("DSR_CONV_BM224");          // read per call: tests switch it inside one process
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0 || (flags & (DSR_F_STATS | DSR_F_PIXSHUF | DSR_F_OUT_NCHW_F32))) return false;
+  if (!dsr_conv_gemm_use_256(M, NB, fast, false)) return false;
+  if (mode == 2) return true;
+  const long long cus = 256, nt = NB / 256;
+  const long long r256 = (((M + 255) / 256) * nt + cus - 1) / cus, r224 = (((M + 223) / 224) * nt + cus - 1) / cus;
+  return r224 * 7 < r256 * 8;
 }
 
 bool dsr_launch_conv_gemm_persist(const ConvGemmArgs& a, int dtype, hipStream_t st);   // conv_gemm_persist.hip

@@ -55,32 +55,8 @@ KERNEL_LOG = None          # set to a list to record (kind, desc-tuple, start_ev
 _OPS = {"fwd": 0, "dgrad": 1, "wgrad": 2}
 
 
-_sk_buffers = {}           # (device index, stream handle) -> the stream-K workspace attached to that stream (or None)
-
-
-def _sk_attach():
-    """Give the current stream its stream-K workspace (dsr_conv_streamk_attach, include/dsr_hip.h) the first time a convolution
-    is launched on it: 64 MB of fp32 partial-tile slots + flags, zeroed once, owned here for the life of the process.  Layers
-    whose 256x256 tiles leave part of the chip idle in their last round then run as stream-K pieces.  DSR_CONV_STREAMK=0: no
-    workspace is attached and those layers run one tile per block."""
-    st = torch.cuda.current_stream()
-    key = (st.device.index, st.cuda_stream)
-    if key in _sk_buffers:
-        return
-    buf = None
-    if os.environ.get("DSR_CONV_STREAMK", "1") != "0":
-        lib = _lib.lib()
-        n = lib.dsr_conv_streamk_bytes()
-        if n:
-            buf = torch.zeros(n, dtype=torch.uint8, device=st.device)
-            check(lib.dsr_conv_streamk_attach(C.c_void_p(st.cuda_stream), _ptr(buf), n))
-    _sk_buffers[key] = buf
-
-
 def _timed(kind, desc, fn, ep=None, name=None):
     """Run one C-ABI conv call; when KERNEL_LOG is a list, bracket it with HIP events on the launch stream."""
-    if kind != "wgrad":
-        _sk_attach()
     if KERNEL_LOG is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -126,13 +126,6 @@ size_t dsr_conv_wgrad_batched_workspace(int count, const dsr_conv_desc* descs, f
 int dsr_conv_wgrad_batched(int count, const dsr_conv_desc* descs, const void* const* xs, const void* const* dys,
                            float* const* dws, void* workspace, size_t ws_bytes, dsr_stream_t s);
 const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, const dsr_epilogue* e);
-/* Stream-K workspace.  Layers whose 256x256 output tiles do not fill whole rounds of the chip (VGG19 conv3_x / conv4_x at
- * batch 32: 392 / 196 tiles on 256 CUs, utils/GAN.py:30-49) are cut into equal K-step shares per CU; partial tiles travel
- * through a caller-owned buffer of dsr_conv_streamk_bytes() bytes, ZERO-INITIALISED ONCE (the kernel leaves it clean),
- * attached to the stream the convolutions are launched on.  One buffer per stream (launches of two streams may overlap);
- * a null workspace detaches.  Without an attached buffer the same layers run one tile per block. */
-size_t dsr_conv_streamk_bytes(void);
-int dsr_conv_streamk_attach(dsr_stream_t s, void* workspace, size_t bytes);
 
 /* ------------------------------------------------------------------ pointwise / reductions (pointwise.hip)
  * nn.BatchNorm2d / PReLU / LeakyReLU / Tanh / Sigmoid / residual add / PixelShuffle backward / losses / Adam.

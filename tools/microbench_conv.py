@@ -62,7 +62,6 @@ def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     dev = torch.device("cuda:0")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    F._sk_attach()          # the stream-K workspace of this stream, as functional attaches it before its own conv launches
     print(f"{'layer':28s} {'GFLOP':>8s} | {'fwd ms':>8s} {'TF':>6s} | {'dgrad ms':>8s} {'TF':>6s} | {'wgrad ms':>8s} {'TF':>6s}")
     for name, n, h, w, cin, cout, k, s, p in SHAPES:
         if flt and flt not in name:
