@@ -24,6 +24,12 @@ Extra legs (rank 0, N = 1 only; each can be switched off):
                   sample of the same workload: warm-up + >= 3 timed steps.
   psnr_delta_db : |PSNR(HIP output, HR) - PSNR(oracle fp32 output, HR)| after K identical steps from identical closed-form
                   weights and inputs, on the reduced configuration named in `psnr_delta.config`.
+  other_workloads : (default workload only) the other three configurations, 3 warm-up + 20 timed steps each in this same
+                  process: {name: {ms_per_step, value, step_frac}} -- so that every throughput figure DESIGN.md quotes is
+                  timed by whoever runs this file, not only by its author.
+  fed_from_patch_bank : (default workload only) the same step with its LR / HR batch cut fresh from an HBM-resident uint8
+                  image bank before every step (dataset.PatchBank: the real-data path, dataset.py:121-159) instead of one
+                  resident synthetic batch -- `value` above keeps the resident-batch definition, this reports the other.
 """
 import argparse
 import importlib
@@ -158,6 +164,7 @@ def build_step(workload, dev, world):
     out, px = finish(step, n * (s * f) ** 2, world == 1 and graphs_on() and os.environ.get("DSR_GAN_GRAPH", "1") != "0"
                      and os.environ.get("DSR_DIST_FORCE", "0") != "1")
     out.modules, out.syncs = [gen, disc], [sync_g, sync_d]
+    out.inputs = (lr, hr)
     # the roofline leg times kernels one at a time: on the single-stream form of the same step (identical launches,
     # identical arithmetic) a launch's HIP-event bracket is not stretched by kernels of the other stream
     out.eager = lambda: steps.gan_step(gen, disc, perc, opt_g, opt_d, lr, hr, sync_g, sync_d, overlap=False)[1]
@@ -430,6 +437,54 @@ def roofline(step, workload, ms_per_step):
             "families": {k: {"seconds": v[0], "tflops": v[1] / v[0] / 1e12, "launches": v[2]} for k, v in fam.items()}}
 
 
+def time_workload(name, dev, steps=20, warmup=3):
+    """ms per step of one of the other workloads in this process (same timing rule: sync on both sides of `steps` steps)."""
+    step, px = build_step(name, dev, 1)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    step_tf = WORKLOADS[name]["gflop"] / ms
+    return {"ms_per_step": ms, "value": px / ms / 1e3, "unit": "HR Mpixels/s", "steps": steps, "warmup": warmup,
+            "step_frac": step_tf / MFMA_BF16_PEAK_TFLOPS, "hip_graph": bool(isinstance(step, _Callable)),
+            "workload": WORKLOADS[name]["desc"]}
+
+
+def time_fed_from_patch_bank(step, dev, steps, px):
+    """The config-3 step with a FRESH batch per step: 32 LR / HR patch pairs cut from an HBM-resident uint8 image bank
+    (dataset.PatchBank: host-side draws of image and position + two byte-kernel launches) and copied into the step's input
+    tensors, then the same (graph-replayed) step.  100 pre-shrunk pairs of 170x255 / 680x1020 pixels: a DIV2K x8 file halved
+    twice, as the reference's loader shrinks them (dataset.py:24-49)."""
+    import numpy as np
+    DS, Dg = P("dataset"), P("utils.degradation")
+    lr, hr = step.inputs
+    rng = np.random.RandomState(0)
+    pairs = []
+    for _ in range(100):
+        img = torch.from_numpy(rng.randint(0, 256, (170, 255, 3), dtype=np.uint8)).to(dev)
+        pairs.append((img, Dg.resize(img, 255 * 4, 170 * 4)))
+    bank = DS.PatchBank(pairs, 4, (lr.shape[3], lr.shape[2]), reference_scaling=False, rng=np.random.RandomState(1))
+
+    def fed():
+        a, b = bank.sample(lr.shape[0])
+        lr.copy_(a)
+        hr.copy_(b)
+        return step()
+    fed()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fed()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": ms, "value": px / ms / 1e3, "unit": "HR Mpixels/s", "steps": steps,
+            "feed": "PatchBank.sample(32) from 100 HBM-resident uint8 pairs + copy into the step's inputs, every step"}
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process tree (this process has not
     touched the GPU and never will) and hand back rank 0's output and exit code."""
@@ -450,6 +505,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -578,6 +634,13 @@ def main():
         pd = psnr_delta(a.workload, dev)
         out["psnr_delta_db"] = pd["value"]
         out["psnr_delta"] = pd
+    if rank == 0 and world == 1 and not force and a.workload == "gan_x4" and not a.no_other_workloads:
+        note("the same step fed from a PatchBank")
+        out["fed_from_patch_bank"] = time_fed_from_patch_bank(step, dev, a.steps, px_per_rank)
+        out["other_workloads"] = {}
+        for name in ("gen_l1_x4", "infer_x8", "dip_x2"):
+            note(f"other workload {name}")
+            out["other_workloads"][name] = time_workload(name, dev)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         note("cpu baseline (oracle on host cores)")
         out["cpu_baseline"] = cpu_baseline(a.workload)

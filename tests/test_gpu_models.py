@@ -727,7 +727,7 @@ def test_two_rank_gan_step_rehearsal(dev):
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--no-cpu-baseline", "--no-roofline"]
+           "--no-cpu-baseline", "--no-roofline", "--no-other-workloads"]
     import json
     import re
     sums = {}
@@ -857,7 +857,8 @@ def test_rccl_single_rank_gan_step(dev):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
+           "--no-other-workloads"]
     sums = {}
     # (plain: eager like the two distributed runs -- a graph-replayed bench takes three more warm-up steps)
     for tag, extra in (("plain", dict(DSR_BENCH_CHECKSUM="1", DSR_GAN_GRAPH="0")), ("gather", dict(DSR_DIST_FORCE="1")),
