@@ -222,6 +222,24 @@ struct DgradS2Args {
 bool dsr_dgrad_s2_supported(int KH, int KW, int stride, int pad, int pad_mode, int H, int W, int CinP, int CoutP, int N);
 void dsr_launch_dgrad_s2(DgradS2Args& a, int N, int dtype, hipStream_t st);
 
+// 3x3 stride-1 pad-1 conv with 64 output channels and CinP = 32 k input channels, halo-staged per 32-channel K-block
+// (conv_halo64.hip)
+struct Halo64Args {
+  const void* x;      // [N][H][W][CinP]
+  const void* w;      // [9][64 rows = output channels][CinP]
+  void* y;            // [N][H][W][64]
+  const float* bias;  // [64] or null
+  int H, W, CinP;
+  int mirror;         // 1: weight slice t sits at the mirrored halo offset (input gradient on the [tap][ci][co] image)
+  int act;
+  float slope;
+  int flags;          // DSR_F_BIAS
+  int kblocks, tiles_y, tiles_x, ntiles;      // filled by the launcher
+  unsigned w_bytes, y_bytes;
+};
+bool dsr_halo64_supported(int KH, int KW, int stride, int pad, int pad_mode, int H, int W, int CinP, int CoutP);
+void dsr_launch_conv_halo64(Halo64Args& a, int N, int dtype, hipStream_t st);
+
 // fused backward of a first layer (conv_first_bwd.hip)
 struct FirstBwdArgs {
   const void* x;       // [N][H][W][8]

@@ -80,6 +80,8 @@ CONV_CASES = [
     ("d_first", 2, 3, 64, 16, 24, 3, 1, 1, 0, "leaky"),
     ("d_first_ragged", 3, 3, 64, 37, 70, 3, 1, 1, 0, "leaky"),
     ("c64_wide_192", 2, 64, 192, 19, 45, 3, 1, 1, 0, "relu"),          # weights-in-registers kernel, 3 output slices
+    ("ps_64_256_ragged", 2, 64, 256, 21, 75, 3, 1, 1, 0, "leaky"),       # input gradient: halo-staged 64-output kernel, 256 channels in, ragged tiles
+    ("d_b1_64_128", 1, 64, 128, 16, 64, 3, 1, 1, 0, "none"),            # ... 128 channels in, exactly one tile row of 2 x 1 tiles
     ("d_s2_64", 2, 64, 64, 16, 16, 3, 2, 1, 0, "none"),
     ("d_s2_odd", 1, 64, 128, 15, 17, 3, 2, 1, 0, "none"),
     ("d_128_256", 1, 128, 256, 8, 8, 3, 1, 1, 0, "relu"),
@@ -650,6 +652,51 @@ def test_conv_256x256_tile_equals_128x128(dev, op):
         ref_st = torch.stack([pre.double().sum((0, 2, 3)), (pre.double() ** 2).sum((0, 2, 3))])
         for mode, s_ in stats.items():
             assert float((s_.cpu() - ref_st).abs().max() / ref_st.abs().max()) < 1e-4, mode
+
+
+@pytest.mark.parametrize("n,h,w,cout", [(3, 40, 100, 256), (2, 8, 32, 128), (1, 67, 130, 192), (40, 16, 64, 256)])
+def test_conv_halo64_dgrad_vs_gather_kernel_and_fp32(dev, n, h, w, cout):
+    """conv_halo64_kernel (input gradient of a 3x3 stride-1 layer with 64 inputs and `cout` = 128 / 192 / 256 outputs: a
+    64-output convolution over `cout` channels, halo staged per 32-channel K-block; generator.py:30, discriminator.py:31)
+    against the gather kernel it replaces (DSR_CONV_HALO64=0: the same products, summed tap-major there and channel-block-major
+    here, so equal within fp32 summation order) and against a float64 conv_transpose2d of the same bf16 operands.  Shapes:
+    ragged right / bottom tiles, the smallest admitted map, 192 = six K-blocks, and 640 tiles on 256 persistent blocks."""
+    import ctypes as C
+    import os
+    L = P("_lib")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    cin = 64
+    d = L.ConvDesc(L.BF16, n, h, w, cin, cout, 3, 3, 1, 1, 0)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    wt = bfr((torch.rand(cout, cin, 3, 3, generator=g) - 0.5) * 0.2)
+    wf = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 0), dtype=torch.bfloat16, device=dev)
+    wd = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 1), dtype=torch.bfloat16, device=dev)
+    L.check(lib.dsr_conv_pack_weight(C.byref(d), wt.to(dev).data_ptr(), wf.data_ptr(), wd.data_ptr(), st))
+    dy = bfr(torch.rand(n, cout, h, w, generator=g) - 0.5)
+    dyg = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)
+    outs = {}
+    old = os.environ.get("DSR_CONV_HALO64")
+    try:
+        for mode in ("1", "0"):
+            os.environ["DSR_CONV_HALO64"] = mode
+            name = lib.dsr_conv_kernel_name(C.byref(d), 1, None).decode()
+            assert ("halo64" in name) == (mode == "1"), (mode, name)
+            dx = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
+            L.check(lib.dsr_conv_dgrad(C.byref(d), dyg.data_ptr(), wd.data_ptr(), dx.data_ptr(), None, 0, st))
+            outs[mode] = dx
+    finally:
+        if old is None:
+            os.environ.pop("DSR_CONV_HALO64", None)
+        else:
+            os.environ["DSR_CONV_HALO64"] = old
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs["1"].float()).all()
+    ref = TF.conv_transpose2d(dy.double(), wt.double(), padding=1)
+    for mode, o in outs.items():
+        assert rel_err(o.float().cpu().permute(0, 3, 1, 2), ref) <= 6e-3, mode       # one bf16 rounding of the output
+    assert rel_err(outs["1"].float(), outs["0"].float()) <= 2.0 ** -7
+    assert float((outs["1"].float() != outs["0"].float()).float().mean()) < 0.05          # (different summation order: a few last bits)
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 64, 96, 64, 64), (1, 50, 38, 128, 192), (3, 32, 32, 256, 64)])
