@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libdsr_hip.so")
 
-ABI_VERSION = 5          # bumped whenever a signature in include/dsr_hip.h changes; checked against the loaded library
+ABI_VERSION = 6          # bumped whenever a signature in include/dsr_hip.h changes; checked against the loaded library
 BF16, F16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_PRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_ELU = range(7)
 PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = range(3)
@@ -53,6 +53,7 @@ SIGNATURES = {
     "dsr_conv_first_bwd_supported": (_I, [_DESC, _I]),
     "dsr_conv_first_bwd_workspace": (_Z, [_DESC]),
     "dsr_conv_first_bwd": (_I, [_DESC, _P, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
+    "dsr_conv_first_bwd_recompute": (_I, [_DESC, _P, _P, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     "dsr_conv_out_size": (_I, [_DESC, C.POINTER(_I), C.POINTER(_I)]),
     "dsr_conv_stats_rows": (_I, [_DESC]),
     "dsr_conv_packed_elems": (_Z, [_DESC, _I]),

@@ -10,6 +10,11 @@
 //   * issues 8 MFMAs per wave (both operands by transposing LDS reads, as in the other weight-gradient kernels).
 // It reads dout and y once (2 x 128 B per pixel) and nothing else of that size; the old path (act_bwd + colsum +
 // wgrad) moved 5 such tensors.  Deterministic: one partial [64][32] per block, folded by first_bwd_finalize_kernel.
+//
+// RC (dsr_conv_first_bwd_recompute): y is not read at all.  The only thing the kernel needs from it is the SIGN of the
+// pre-activation, and the im2col image it builds anyway IS the forward layer's A operand: one more MFMA K-step per
+// (16 pixels x 16 channels) against the layer's own 27 x 64 weights recomputes v = conv(x) + b in fp32, and g = dout * act'(v).
+// The 1.07 GB activation of D's first layer (config 3) is then read by this pass no more: 2.15 -> 1.1 GB.
 #include <stdlib.h>
 
 #include "../../include/dsr_hip.h"
@@ -32,11 +37,13 @@ __device__ __forceinline__ s16x4 fb_tr_read(const unsigned char* p) {
 // NS = 2: two stages, the next tile's DMA under this tile's work, two blocks per CU (74 KB).  NS = 1: one stage, FOUR blocks
 // per CU (37 KB): a tile's phases are short dependent LDS round trips between barriers, so what hides them is more resident
 // waves, and the other three blocks cover a block's DMA wait as well as a second stage would.
-template <int DT, int NS>
-__global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_first_bwd_kernel(const FirstBwdArgs a) {
+template <int DT, int NS, bool RC = false>
+__global__ __launch_bounds__(256, RC ? 5 : (NS == 1 ? 4 : 2)) void conv_first_bwd_kernel(const FirstBwdArgs a) {
   // stage s: [dout tile | y tile | image halo]; the im2col image is built over the y tile once g has been formed
   static_assert(FB_B <= FB_T, "im2col image must fit in the y tile");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * FB_STAGE];
+  // (RC: no y tile is fetched -- the im2col image lives where it would be, in 8 of its 16 KB: 29 KB per block, FIVE blocks per CU)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RC ? FB_T + FB_B + FB_XRAW : NS * FB_STAGE];
+  constexpr int XOFF = RC ? FB_T + FB_B : 2 * FB_T;                  // the image halo's place in a stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
@@ -60,7 +67,8 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_first_bwd_kernel(co
       const bool ok = oy < a.H && ox < a.W;
       const unsigned off = ok ? (unsigned)((((n * a.H + oy) * a.W + ox) * 64 + chunk * 8) * 2) : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(drsrc, (lds_ptr)(st + (32 * u + 8 * wave) * 128), 16, off, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr)(st + FB_T + (32 * u + 8 * wave) * 128), 16, off, 0, 0, 0);
+      if constexpr (!RC)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr)(st + FB_T + (32 * u + 8 * wave) * 128), 16, off, 0, 0, 0);
     }
     {                                                                // halo: 264 pixels of 16 B = 5 pieces (waves 0..3 + wave 0 again)
 #pragma unroll
@@ -71,13 +79,31 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_first_bwd_kernel(co
           const int hr = q / FB_HC, hc = q - hr * FB_HC;
           const int iy = oy0 - 1 + hr, ix = ox0 - 1 + hc;
           const bool ok = q < FB_HR * FB_HC && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(st + 2 * FB_T + piece * 1024), 16,
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(st + XOFF + piece * 1024), 16,
                                                    ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * 8) * 2) : OOB, 0, 0, 0);
         }
       }
     }
   };
 
+  // RC: this wave's 16 output channels of the layer's weights as ONE MFMA A fragment (rows co = 16 wave + l16, k = column
+  // 3 tap + ci of the im2col image; the 16-bit rounding the forward's packed weights went through), and its fp32 bias
+  [[maybe_unused]] U4 fw0 = U4{0u, 0u, 0u, 0u};
+  [[maybe_unused]] f32x4 bias0 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (RC) {
+    unsigned short e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int col = 8 * g + i;
+      const int tap = col / 3, ci = col - 3 * tap;
+      e[i] = (col < 27 && ci < a.Cin) ? f2h<DT>(a.w0[((16 * wave + l16) * a.Cin + ci) * 9 + tap]) : (unsigned short)0;
+    }
+    fw0.x = e[0] | ((unsigned)e[1] << 16);
+    fw0.y = e[2] | ((unsigned)e[3] << 16);
+    fw0.z = e[4] | ((unsigned)e[5] << 16);
+    fw0.w = e[6] | ((unsigned)e[7] << 16);
+    if (a.b0) bias0 = f32x4{a.b0[16 * wave + 4 * g], a.b0[16 * wave + 4 * g + 1], a.b0[16 * wave + 4 * g + 2], a.b0[16 * wave + 4 * g + 3]};
+  }
   f32x4 acc[2];
   acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
   int t = blockIdx.x;
@@ -95,6 +121,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_first_bwd_kernel(co
     if (NS == 2 && t + (int)gridDim.x < a.ntiles) dma(t + gridDim.x, buf ^ 1);
     unsigned char* st = smem + buf * FB_STAGE;
     // ---- g = dout * act'(y), in place (4 chunks per thread; slot (p, pos) holds channel chunk pos ^ (p & 7) in both tiles)
+    if constexpr (!RC) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int off = (tid + 256 * u) * 16;
@@ -110,6 +137,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_first_bwd_kernel(co
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                    // every thread is done reading the y tile
     asm volatile("" ::: "memory");
+    }
     unsigned char* sBim = st + FB_T;
     // ---- im2col image: row p (64 B), chunk c = 8 columns col = 3*tap + ci; col 27 = 1, 28..31 = 0
 #pragma unroll
@@ -117,7 +145,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_first_bwd_kernel(co
       const int idx = tid + 256 * u;                                 // 128 pixels x 4 chunks
       const int p = idx >> 2, c = idx & 3;
       const int row = p >> 6, xx = p & 63;
-      const unsigned char* xr = st + 2 * FB_T;
+      const unsigned char* xr = st + XOFF;
       unsigned short e[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -135,6 +163,31 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_first_bwd_kernel(co
       v.z = e[4] | ((unsigned)e[5] << 16);
       v.w = e[6] | ((unsigned)e[7] << 16);
       *reinterpret_cast<U4*>(sBim + p * 64 + ((c ^ ((p >> 1) & 3)) << 4)) = v;
+    }
+    if constexpr (RC) {
+      if (a.act != DSR_ACT_NONE) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // the im2col image is complete
+        asm volatile("" ::: "memory");
+        // ---- v[co][p] = W0[co][:] . im2col[p][:] + b (weights as the A operand: a lane ends up with 4 consecutive channels
+        // 16 wave + 4 g .. + 3 of pixel 16 pg + l16 = 8 contiguous bytes of that pixel's dout row), g = dout * act'(v) in place
+#pragma unroll
+        for (int pg = 0; pg < 8; ++pg) {
+          const int p = 16 * pg + l16;
+          const U4 fa = *reinterpret_cast<const U4*>(sBim + p * 64 + ((g ^ ((p >> 1) & 3)) << 4));
+          const f32x4 v = mfma16<DT>(fw0, fa, bias0);
+          unsigned char* dp = st + p * 128 + (((2 * wave + (g >> 1)) ^ (p & 7)) << 4) + (g & 1) * 8;
+          const uint2 dv = *reinterpret_cast<const uint2*>(dp);
+          float d0 = h2f<DT>((unsigned short)(dv.x & 0xffff)) * act_grad_from_out(a.act, v[0], a.slope);
+          float d1 = h2f<DT>((unsigned short)(dv.x >> 16)) * act_grad_from_out(a.act, v[1], a.slope);
+          float d2 = h2f<DT>((unsigned short)(dv.y & 0xffff)) * act_grad_from_out(a.act, v[2], a.slope);
+          float d3 = h2f<DT>((unsigned short)(dv.y >> 16)) * act_grad_from_out(a.act, v[3], a.slope);
+          uint2 o;
+          o.x = (unsigned)f2h<DT>(d0) | ((unsigned)f2h<DT>(d1) << 16);
+          o.y = (unsigned)f2h<DT>(d2) | ((unsigned)f2h<DT>(d3) << 16);
+          *reinterpret_cast<uint2*>(dp) = o;
+        }
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                    // g and the im2col image are complete
@@ -204,7 +257,10 @@ static int first_bwd_stages() {          // tuning switch DSR_FIRST_BWD_STAGES: 
   const char* e = getenv("DSR_FIRST_BWD_STAGES");
   return (e && e[0] == '2') ? 2 : 1;
 }
-static int first_bwd_blocks(long long ntiles) { return (int)(ntiles < 1024 ? ntiles : 1024); }   // (four resident blocks per CU)
+static int first_bwd_blocks(long long ntiles, bool rc = true) {      // four (five: recompute form) resident blocks per CU
+  const long long cap = rc ? 1280 : 1024;
+  return (int)(ntiles < cap ? ntiles : cap);
+}
 
 extern "C" size_t dsr_conv_first_bwd_workspace(const dsr_conv_desc* d) {
   if (!d) return 0;
@@ -218,11 +274,12 @@ extern "C" int dsr_conv_first_bwd_supported(const dsr_conv_desc* d, int act) {
          (size_t)d->N * d->H * d->W * 128 < (1ull << 31);
 }
 
-extern "C" int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const void* dout, const void* y, int act,
-                                  float slope, float* dw, float* db, void* workspace, size_t ws_bytes, dsr_stream_t s) {
+static int first_bwd_impl(const dsr_conv_desc* d, const void* x, const void* dout, const void* y, const float* w0, const float* b0,
+                          int act, float slope, float* dw, float* db, void* workspace, size_t ws_bytes, dsr_stream_t s) {
+  const bool rc = w0 != nullptr;
   if (!dsr_conv_first_bwd_supported(d, act)) return dsr_fail(DSR_E_UNSUPPORTED, "conv_first_bwd: unsupported layer");
-  if (!x || !dout || !y || !dw) return dsr_fail(DSR_E_ARG, "conv_first_bwd: null pointer");
-  if (act == DSR_ACT_LEAKY && !(slope > 0.f))   // the derivative is read off the stored output: needs slope > 0
+  if (!x || !dout || (!y && !rc) || !dw) return dsr_fail(DSR_E_ARG, "conv_first_bwd: null pointer");
+  if (act == DSR_ACT_LEAKY && !rc && !(slope > 0.f))   // the derivative is read off the stored output: needs slope > 0
     return dsr_fail(DSR_E_ARG, "conv_first_bwd: LeakyReLU slope %g must be > 0", (double)slope);
   const size_t need = dsr_conv_first_bwd_workspace(d);
   if (!workspace || ws_bytes < need) return dsr_fail(DSR_E_WORKSPACE, "conv_first_bwd: workspace %zu < %zu", ws_bytes, need);
@@ -236,14 +293,22 @@ extern "C" int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const v
   a.W = d->W;
   a.act = act;
   a.slope = slope;
+  a.w0 = w0;
+  a.b0 = b0;
+  a.Cin = d->Cin;
   a.tiles_y = (d->H + FB_TR - 1) / FB_TR;
   a.tiles_x = (d->W + FB_TW - 1) / FB_TW;
   a.ntiles = d->N * a.tiles_y * a.tiles_x;
   a.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * 16);
   a.y_bytes = (unsigned)((size_t)d->N * d->H * d->W * 128);
-  const int blocks = first_bwd_blocks(a.ntiles);
+  const int blocks = first_bwd_blocks(a.ntiles, rc);
   const bool two = first_bwd_stages() == 2;
-  if (d->dtype == DSR_BF16) {
+  if (rc) {      // (one stage, four blocks per CU: 29 KB of LDS each)
+    if (d->dtype == DSR_BF16)
+      hipLaunchKernelGGL((conv_first_bwd_kernel<DSR_DTYPE_BF16, 1, true>), dim3(blocks), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((conv_first_bwd_kernel<DSR_DTYPE_F16, 1, true>), dim3(blocks), dim3(256), 0, s, a);
+  } else if (d->dtype == DSR_BF16) {
     if (two)
       hipLaunchKernelGGL((conv_first_bwd_kernel<DSR_DTYPE_BF16, 2>), dim3(blocks), dim3(256), 0, s, a);
     else
@@ -256,4 +321,18 @@ extern "C" int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const v
   }
   hipLaunchKernelGGL(first_bwd_finalize_kernel, dim3(64), dim3(256), 0, s, (const float*)workspace, blocks, d->Cin, dw, db);
   return dsr_launch_status("dsr_conv_first_bwd");
+}
+
+extern "C" int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const void* dout, const void* y, int act,
+                                  float slope, float* dw, float* db, void* workspace, size_t ws_bytes, dsr_stream_t s) {
+  return first_bwd_impl(d, x, dout, y, nullptr, nullptr, act, slope, dw, db, workspace, ws_bytes, s);
+}
+
+// The same pass without the activation output: the sign of the pre-activation is recomputed from the image and the layer's own
+// fp32 weights `w` (OIHW [64][Cin][3][3]) and bias (nullable) -- see the RC note at the top of this file.
+extern "C" int dsr_conv_first_bwd_recompute(const dsr_conv_desc* d, const void* x, const void* dout, const float* w,
+                                            const float* bias, int act, float slope, float* dw, float* db, void* workspace,
+                                            size_t ws_bytes, dsr_stream_t s) {
+  if (!w) return dsr_fail(DSR_E_ARG, "conv_first_bwd_recompute: null weight pointer");
+  return first_bwd_impl(d, x, dout, nullptr, w, bias, act, slope, dw, db, workspace, ws_bytes, s);
 }

@@ -250,6 +250,9 @@ struct FirstBwdArgs {
   float slope;
   int tiles_y, tiles_x, ntiles;
   unsigned x_bytes, y_bytes;
+  const float* w0;     // recompute form: the layer's fp32 OIHW weights [64][Cin][3][3] and bias (nullable); y is not read
+  const float* b0;
+  int Cin;
 };
 
 void dsr_launch_wgrad_reduce(const float* partial, float* dw, int splits, int ntaps, int Cout, int Cin, int CoutP,

