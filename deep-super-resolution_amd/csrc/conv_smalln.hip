@@ -164,21 +164,32 @@ __global__ __launch_bounds__(512, 2) void conv_smalln_kernel(const SmallNArgs a)
 //     T_G[p][(d, co)] = sum_kh sum_ci in[y + kh][p][ci] * W[kh][kwbase_G + d][ci][co]         (p = input column)
 // is one GEMM with N = 5 shifts x 3 channels = 15 columns and K = 9 x 64, and the output is the diagonal sum
 //     out[y][x][co] = sum_G sum_d T_G[x + kwbase_G + d][(d, co)].
-// 108 MFMAs and 90 fragment reads per 32 output pixels instead of 324 and 486.  T is written to LDS (aliasing the
-// halo, which is dead by then) with a 17-float row pitch and summed by the wave that produced it.
+// 108 MFMAs per 32 output pixels instead of 324.  T is written to LDS (aliasing a consumed halo stage) with a 17-float row
+// pitch and summed by the wave that produced it.
+// Round 3 form (the one-row-per-wave, register-staged form before it ran at 0.14 of the MFMA peak, bound by the LDS port:
+// 90 fragment reads per 108 MFMAs, and by its 2.5x halo):
+//   * tile = 16 rows x 32 columns; the input channels are walked in two K-blocks of 32 (64 bytes per pixel: a wave's
+//     fragment read covers 16 consecutive pixels = 1 KB contiguous, no swizzle, and a K-block is one mfma_f32_16x16x32), so
+//     the 24 x 40 halo of one K-block is 60 KB and TWO stages fit beside the 36 KB of weights: the next K-block's (next
+//     tile's) halo arrives by LDS-DMA under this one's MFMAs instead of through registers;
+//   * a wave owns TWO output rows: the A fragments of halo row h serve row y0 (tap row h - y0) and row y0 + 1 (tap row
+//     h - y0 - 1), and the B fragments of a tap row are read once and kept for the next halo row -- 30 + 18 fragment reads per
+//     108 MFMAs (0.44 per MFMA instead of 0.83); halo overhead 1.9x instead of 2.5x.
 template <int DT>
 __global__ __launch_bounds__(512, 2) void conv_toeplitz9_kernel(const SmallNArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int TR = 8, HR = TR + 8, HC = 40;
+  constexpr int TR = 16, HR = TR + 8, HC = 40;
   constexpr int W_BYTES = 18 * 16 * 128;                 // [kh][group][16 rows][64 ci], chunks XOR-swizzled by row
+  constexpr int HALO = HR * HC * 64;                     // one K-block of the halo: 61,440 B = 60 DMA pieces
+  constexpr int NP = HALO / 1024;
   constexpr int T_PITCH = 17, T_WAVE = 2 * 48 * T_PITCH; // floats per wave: [group][48 p][17]
+  static_assert(8 * T_WAVE * 4 <= HALO, "the T slabs of the 8 waves alias one halo stage");
   unsigned char* sW = smem;
-  unsigned char* sX = smem + W_BYTES;                    // [HR][HC][64 ch] (80 KB); reused as float sT[8 waves][T_WAVE]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* sX = smem + W_BYTES;                    // two halo stages
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r16 = lane & 15;
   const int per_img = a.tiles_y * a.tiles_x;
   const unsigned short* __restrict__ Wg = reinterpret_cast<const unsigned short*>(a.w);
-  const int c = tid & 7, pb = tid >> 3;
 
   // weights: LDS row (kh, G, n = 3d + co) <- packed slice [tap = 9kh + kwbase + d][row co]; unused rows are zero
   for (int i = tid; i < 18 * 16 * 8; i += 512) {
@@ -191,115 +202,151 @@ __global__ __launch_bounds__(512, 2) void conv_toeplitz9_kernel(const SmallNArgs
     if (ok) v = reinterpret_cast<const U4*>(Wg)[((kh * 9 + kw) * a.NB + co) * 8 + ch];
     *reinterpret_cast<U4*>(sW + (kg * 16 + row) * 128 + ((ch ^ (row & 7)) << 4)) = v;
   }
-  int b_off[2];                                          // B fragment: row r16, k-chunk 4kk + g
+  // B fragments (row r16, k-chunk 4 kb + g of K-block kb): ALL 36 of them stay in registers for the life of the block (144
+  // VGPRs) -- every wave needs the same 18 per K-block, and read from LDS they were 18 of a wave's 48 fragment reads per 108 MFMAs
+  __syncthreads();
+  U4 fw[2][9][2];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) b_off[kk] = r16 * 128 + (((4 * kk + g) ^ (r16 & 7)) << 4);
-  int a_off[3][2];                                       // A fragment: input column p = 16f + r16 (clamped to the halo row)
+  for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-  for (int f = 0; f < 3; ++f) {
-    const int p = 16 * f + r16 < HC ? 16 * f + r16 : HC - 1;
+    for (int kh = 0; kh < 9; ++kh)
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) a_off[f][kk] = p * 128 + (((4 * kk + g) ^ (p & 7)) << 4);
-  }
+      for (int G = 0; G < 2; ++G)
+        fw[kb][kh][G] = *reinterpret_cast<const U4*>(sW + (kh * 2 + G) * 16 * 128 + r16 * 128 + (((4 * kb + g) ^ (r16 & 7)) << 4));
+  int a_off[3];                                          // A fragment: input column p = 16f + r16 (clamped to the halo row), chunk g
+#pragma unroll
+  for (int f = 0; f < 3; ++f) a_off[f] = (16 * f + r16 < HC ? 16 * f + r16 : HC - 1) * 64 + 16 * g;
 
-  constexpr int NV = (HR * HC * 8 + 511) / 512;          // 10 halo vectors per thread
-  const int hr0 = pb / HC, hc0 = pb - hr0 * HC;
-  U4 v[NV];
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  // ---- loader: wave w issues the pieces w, w + 8, ... (< 60); lane l of piece p fills slot 16 p + l / 4 (= halo pixel), chunk l % 4
+  // (the slot -> (halo row, column) decode is redone per piece: a dozen integer instructions, against 10 registers that the
+  //  register-resident weights need)
+  constexpr int NU = (NP + 7) / 8;                       // 8
+  const int slot0 = 16 * wave + (lane >> 2);
+  const int chunk_b = (lane & 3) * 16;
+  const unsigned img_bytes = (unsigned)(a.IH * a.IW * 128);
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  auto fetch = [&](int t) {
-    const int n = t / per_img;
-    const int rem = t - n * per_img;
-    const int oy0 = (rem / a.tiles_x) * TR - 4, ox0 = (rem % a.tiles_x) * 32 - 4;
-    int hr = hr0, hc = hc0;
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int iy = oy0 + hr, ix = ox0 + hc;
-      const bool ok = hr < HR && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-      v[u] = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(
-                                        xrsrc, ok ? (unsigned)((((n * a.IH + iy) * a.IW + ix) * 64 + c * 8) * 2) : OOB, 0, 0));
-      hc += 64;
-      while (hc >= HC) {
-        hc -= HC;
-        ++hr;
-      }
-    }
+  struct TileXY {
+    int n, ty, tx;
   };
-  auto stash = [&]() {
-    int hr = hr0, hc = hc0;
+  // (tile order: image, tile row, column (fastest), blocks in launch order.  An XCD-aware order with the tile row fastest -- the
+  //  32 blocks of an XCD on one column strip, halo overlap served by that XCD's L2 -- measured 7 % SLOWER: 0.617 vs 0.579 ms)
+  auto decomp = [&](int t) {
+    TileXY c;
+    c.n = t / per_img;
+    const int rem = t - c.n * per_img;
+    c.ty = rem / a.tiles_x;
+    c.tx = rem - c.ty * a.tiles_x;
+    return c;
+  };
+  auto fetch = [&](const TileXY& tc, int kb, int buf) {
+    const int oy0 = tc.ty * TR - 4, ox0 = tc.tx * 32 - 4;
+    // per-image resource: halo rows above / below the image fall outside it and read as zeros
+    const BufSrd xsrd = make_srd(reinterpret_cast<const unsigned char*>(a.x) + (size_t)tc.n * img_bytes, img_bytes);
+    const int sbase = (oy0 * a.IW + ox0) * 128 + kb * 64;
+    const bool interior = ox0 >= 0 && ox0 + HC <= a.IW;
+    unsigned char* dst = sX + buf * HALO;
+    int s0 = slot0;
+    asm volatile("" : "+v"(s0));                         // (opaque: keeps the decode below from being hoisted out of the tile loop)
 #pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int q = hr * HC + hc;
-      if (hr < HR) *reinterpret_cast<U4*>(sX + q * 128 + ((c ^ (q & 7)) << 4)) = v[u];
-      hc += 64;
-      while (hc >= HC) {
-        hc -= HC;
-        ++hr;
-      }
+    for (int u = 0; u < NU; ++u) {
+      if (wave + 8 * u >= NP) continue;                  // (wave-uniform; only the last round is partial)
+      const int slot = s0 + 128 * u;
+      const int hr = slot / HC, hc = slot - hr * HC;
+      unsigned off = (unsigned)((hr * a.IW + hc) * 128 + chunk_b + sbase);
+      if (!interior && (unsigned)(ox0 + hc) >= (unsigned)a.IW) off = OOB;
+      lds_dma16(xsrd, dst + (wave + 8 * u) * 1024, off);
     }
   };
   const float slope = a.prelu ? a.prelu[0] : a.slope;
-  float* sT = reinterpret_cast<float*>(sX) + wave * T_WAVE;
 
-  int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tstep = gridDim.x;
-  if (t < a.ntiles) fetch(t);
+  int t = blockIdx.x;
+  if (t >= a.ntiles) return;
+  TileXY cur = decomp(t);
+  fetch(cur, 0, 0);
+  int buf = 0;
+  const bool late = wave >= 4;                           // (one wave's DMA issue runs under its SIMD partner's MFMAs)
   for (; t < a.ntiles; t += tstep) {
-    __syncthreads();                                     // previous tile's T reads are done (and sW is written)
-    stash();
-    __syncthreads();
-    if (t + tstep < a.ntiles) fetch(t + tstep);
-
-    f32x4 acc[3][2];
+    const bool has_next = t + tstep < a.ntiles;
+    const TileXY nxt = has_next ? decomp(t + tstep) : cur;
+    f32x4 acc[2][3][2];
 #pragma unroll
-    for (int f = 0; f < 3; ++f) acc[f][0] = acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-    for (int kh = 0; kh < 9; ++kh) {
-      const unsigned char* rowp = sX + (wave + kh) * HC * 128;
-      const unsigned char* wp = sW + kh * 2 * 16 * 128;
+      for (int f = 0; f < 3; ++f) acc[r][f][0] = acc[r][f][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        U4 fa[3], fb[2];
+    for (int kb = 0; kb < 2; ++kb, buf ^= 1) {
+      // my DMA of this K-block has landed (first step: and my part of sW is written); after the barrier everyone's has, and
+      // every wave is done with the other stage (its T reads of the previous tile included).  Raw barrier: the DMA is issued
+      // by inline asm, the waits are explicit.
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      auto prefetch = [&]() {
+        if (kb == 0)
+          fetch(cur, 1, buf ^ 1);
+        else if (has_next)
+          fetch(nxt, 0, buf ^ 1);
+      };
+      if (!late) prefetch();
+      const unsigned char* rowp = sX + buf * HALO + (2 * wave) * HC * 64;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) fa[f] = *reinterpret_cast<const U4*>(rowp + a_off[f][kk]);
+      for (int hh = 0; hh < 10; ++hh) {
+        U4 fa[3];
 #pragma unroll
-        for (int G = 0; G < 2; ++G) fb[G] = *reinterpret_cast<const U4*>(wp + G * 16 * 128 + b_off[kk]);
+        for (int f = 0; f < 3; ++f) fa[f] = *reinterpret_cast<const U4*>(rowp + hh * HC * 64 + a_off[f]);
+        if (hh < 9) {                                    // row y0: tap row hh
+#pragma unroll
+          for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int G = 0; G < 2; ++G) acc[0][f][G] = mfma16<DT>(fa[f], fw[kb][hh][G], acc[0][f][G]);
+        }
+        if (hh >= 1) {                                   // row y0 + 1: tap row hh - 1
+#pragma unroll
+          for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int G = 0; G < 2; ++G) acc[1][f][G] = mfma16<DT>(fa[f], fw[kb][hh - 1][G], acc[1][f][G]);
+        }
+        if (hh == 2 && late) prefetch();
+      }
+    }
+    // ---- every wave is done with the stage of K-block 1 (buf ^ 1 after the loop's flip): it becomes T; the DMA in flight
+    // targets the other stage
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float* sT = reinterpret_cast<float*>(sX + (buf ^ 1) * HALO) + wave * T_WAVE;
+    const int ox0 = cur.tx * 32;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      // lane (g, r16) holds T_G[p = 16f + 4g + j][n = r16]
+#pragma unroll
+      for (int G = 0; G < 2; ++G)
 #pragma unroll
         for (int f = 0; f < 3; ++f)
 #pragma unroll
-          for (int G = 0; G < 2; ++G) acc[f][G] = mfma16<DT>(fa[f], fb[G], acc[f][G]);
-      }
-    }
-    __syncthreads();                                     // every wave is done with the halo: it becomes T
-    // lane (g, r16) holds T_G[p = 16f + 4g + j][n = r16]
+          for (int j = 0; j < 4; ++j) sT[(G * 48 + 16 * f + 4 * g + j) * T_PITCH + r16] = acc[r][f][G][j];
+      // (the wave reads back only what it wrote itself: LDS operations of one wave complete in order)
+      const int oy = cur.ty * TR + 2 * wave + r;
+      if (lane < 32 && oy < a.OH && ox0 + lane < a.OW) {
+        const int x = lane;
 #pragma unroll
-    for (int G = 0; G < 2; ++G)
+        for (int co = 0; co < 3; ++co) {
+          if (co < a.cout) {
+            float s = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-      for (int f = 0; f < 3; ++f)
+            for (int d = 0; d < 5; ++d) s += sT[(x + d) * T_PITCH + 3 * d + co];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sT[(G * 48 + 16 * f + 4 * g + j) * T_PITCH + r16] = acc[f][G][j];
-    // (the wave reads back only what it wrote itself: LDS operations of one wave complete in order)
-    const int n = t / per_img;
-    const int rem = t - n * per_img;
-    const int oy = (rem / a.tiles_x) * TR + wave, ox0 = (rem % a.tiles_x) * 32;
-    if (lane < 32 && oy < a.OH && ox0 + lane < a.OW) {
-      const int x = lane;
-#pragma unroll
-      for (int co = 0; co < 3; ++co) {
-        if (co < a.cout) {
-          float s = a.bias ? a.bias[co] : 0.f;
-#pragma unroll
-          for (int d = 0; d < 5; ++d) s += sT[(x + d) * T_PITCH + 3 * d + co];
-#pragma unroll
-          for (int d = 0; d < 4; ++d) s += sT[(48 + x + 5 + d) * T_PITCH + 3 * d + co];
-          const float o = act_apply(a.act, s, slope);
-          if (a.out_f32)
-            a.out_f32[(((size_t)n * a.cout + co) * a.OH + oy) * a.OW + ox0 + x] = o;
-          else
-            reinterpret_cast<unsigned short*>(a.y)[((size_t)(n * a.OH + oy) * a.OW + ox0 + x) * a.CoutP + co] = f2h<DT>(o);
+            for (int d = 0; d < 4; ++d) s += sT[(48 + x + 5 + d) * T_PITCH + 3 * d + co];
+            const float o = act_apply(a.act, s, slope);
+            if (a.out_f32)
+              a.out_f32[(((size_t)cur.n * a.cout + co) * a.OH + oy) * a.OW + ox0 + x] = o;
+            else
+              reinterpret_cast<unsigned short*>(a.y)[((size_t)(cur.n * a.OH + oy) * a.OW + ox0 + x) * a.CoutP + co] = f2h<DT>(o);
+          }
         }
       }
     }
+    cur = nxt;
   }
 }
 
@@ -334,9 +381,11 @@ int dsr_launch_conv_smalln(SmallNArgs& a, int N, int dtype, hipStream_t st) {
   if (a.KW == 9 && a.KH == 9 && a.cout <= 3 && a.pad == 4 && !a.flip) {   // the generator's tail: Toeplitz mapping
     static LdsOptIn toeplitz_optin[2];
     const int dj = dtype == DSR_DTYPE_BF16 ? 0 : 1;
-    const size_t tl = 18 * 16 * 128 + 16 * 40 * 128;
+    const size_t tl = 18 * 16 * 128 + 2 * 24 * 40 * 64;      // weights + two one-K-block halo stages
     const void* tf = dj == 0 ? (const void*)conv_toeplitz9_kernel<DSR_DTYPE_BF16> : (const void*)conv_toeplitz9_kernel<DSR_DTYPE_F16>;
     toeplitz_optin[dj].ensure(tf, 160 * 1024);
+    a.tiles_y = (a.OH + 15) / 16;                              // (this kernel's tiles are 16 rows x 32 columns)
+    a.ntiles = N * a.tiles_y * a.tiles_x;
     dim3 tg(a.ntiles < 256 ? a.ntiles : 256);
     if (dj == 0) {
       hipLaunchKernelGGL((conv_toeplitz9_kernel<DSR_DTYPE_BF16>), tg, block, tl, st, a);
