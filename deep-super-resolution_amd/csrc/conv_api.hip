@@ -371,7 +371,7 @@ static int conv_dgrad_impl(const dsr_conv_desc* d, const void* dy, const void* w
     sn.flip = 1;
     if (dsr_launch_conv_smalln(sn, d->N, d->dtype, s)) return dsr_launch_status("dsr_conv_dgrad(small-n)");
   }
-  if (!folded && !mask_x && dsr_halo64_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->H, d->W, r8(d->Cout), r8(d->Cin))) {
+  if (!folded && dsr_halo64_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->H, d->W, r8(d->Cout), r8(d->Cin))) {
     // 64 input channels of a layer with 128 / 256 outputs (PixelShuffle convs, D's 64 -> 128, VGG conv2_1): the gradient is a
     // 64-output convolution over many channels -- halo staged per 32-channel K-block (conv_halo64.hip)
     Halo64Args q;
@@ -384,6 +384,9 @@ static int conv_dgrad_impl(const dsr_conv_desc* d, const void* dy, const void* w
     q.CinP = r8(d->Cout);
     q.mirror = 1;
     q.act = DSR_ACT_NONE;
+    q.mask_x = mask_x;
+    q.mask_act = mask_act;
+    q.mask_slope = mask_slope;
     dsr_launch_conv_halo64(q, d->N, d->dtype, s);
     return dsr_launch_status("dsr_conv_dgrad(halo64)");
   }
@@ -763,7 +766,7 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
     if (is_tail9(d)) return "conv_dgrad_toeplitz9_kernel";
     if (is_smalln_dgrad(d)) return "conv_smalln_kernel";
     if (dsr_halo64_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->H, d->W, r8(d->Cout), r8(d->Cin)))
-      return "conv_halo64_kernel";      // (a masked input gradient of the same shape stays on the gather kernel)
+      return "conv_halo64_kernel";
     if (dsr_dgrad_s2_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->H, d->W, r8(d->Cin), r8(d->Cout), d->N))
       return "conv_dgrad_s2_kernel";
     // input gradient on the gather kernel: grid = the input pixels (stride 1) or one output-parity class of them (stride 2)

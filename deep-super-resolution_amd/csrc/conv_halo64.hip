@@ -114,6 +114,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo64_kernel(const Halo64Args a)
 
   // store loop: thread tid moves the 16-byte vectors tid + 512 it of a 4-row half tile (pixel = vector / 8)
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.mask_x ? a.mask_x : a.y), 0, a.y_bytes, 0x00020000);
   const int cw_base = (16 * wq + r16) * H64_CSTRIDE + (32 * wc + 4 * g) * 2;      // + (row & 3) * 64 * CSTRIDE + nt * 32
   const int cr_base = (tid >> 3) * H64_CSTRIDE + (tid & 7) * 16;                   // + it * 64 * CSTRIDE: row `it` of the half
   const int st_part = ((tid >> 3) & 63) * 128 + (tid & 7) * 16;                     // byte offset inside an output row of the tile
@@ -223,6 +224,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo64_kernel(const Halo64Args a)
         const int row = half * 4 + it;
         unsigned off = sorg + (unsigned)(row * a.W * 128 + st_part);
         if (!full && !(oy0 + row < a.H && ox0 + ((tid >> 3) & 63) < a.W)) off = OOB;
+        if (a.mask_x) {       // (uniform) dsr_conv_dgrad_masked: the stored gradient is multiplied by act'(mask_x), the activation OUTPUT
+                              // this gradient is taken with respect to (same shape as y) -- as conv_gemm.hip's masked stores
+          const U4 o = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, off, 0, 0));
+          __builtin_amdgcn_raw_buffer_store_b128(
+              __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, act_mask8<DT>(v, o, a.mask_act, a.mask_slope)), yrsrc, off, 0, 0);
+          continue;
+        }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), yrsrc, off, 0, 0);
       }
     }

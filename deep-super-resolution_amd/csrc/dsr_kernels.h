@@ -234,11 +234,29 @@ struct Halo64Args {
   int act;
   float slope;
   int flags;          // DSR_F_BIAS
+  const void* mask_x; // optional: y *= mask_act'(mask_x), mask_x an activation output of y's shape (dsr_conv_dgrad_masked)
+  int mask_act;
+  float mask_slope;
   int kblocks, tiles_y, tiles_x, ntiles;      // filled by the launcher
   unsigned w_bytes, y_bytes;
 };
 bool dsr_halo64_supported(int KH, int KW, int stride, int pad, int pad_mode, int H, int W, int CinP, int CoutP);
 void dsr_launch_conv_halo64(Halo64Args& a, int N, int dtype, hipStream_t st);
+
+// the discriminator's first two convolutions in one forward kernel (conv_first2.hip)
+struct First2Args {
+  const void* x;      // [N][H][W][8]
+  const void* w0;     // [9][64][8]   first layer, forward image
+  const float* b0;
+  float slope0;
+  const void* w1;     // [9][64][64]  second layer, forward image
+  const float* b1;
+  void* a0;           // [N][H][W][64] or null
+  void* y1;           // [N][OH][OW][64]
+  float* stats;       // [blocks][2][64] or null
+  int H, W, OH, OW, tiles_y, tiles_x, ntiles;
+  unsigned a0_bytes, y1_bytes;
+};
 
 // fused backward of a first layer (conv_first_bwd.hip)
 struct FirstBwdArgs {

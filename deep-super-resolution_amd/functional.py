@@ -155,6 +155,17 @@ def make_desc(x, cout, kh, kw, stride, pad, pad_mode, cin):
     return ConvDesc(_dt(x), n, h, w, cin, cout, kh, kw, stride, pad, pad_mode)
 
 
+def first2_supported(img, w0, w1, stride1):
+    """The image layer + the stride-2 64 -> 64 layer behind it as one forward kernel (dsr_conv_first2_fwd)?"""
+    if not (img.is_cuda and img.dim() == 4 and img.shape[-1] == 8 and tuple(w0.shape[2:]) == (3, 3) and tuple(w1.shape) == (64, 64, 3, 3)
+            and w0.shape[0] == 64 and w0.shape[1] <= 8 and stride1 == 2):
+        return False
+    n, h, w, _ = img.shape
+    d0 = ConvDesc(_dt(img), n, h, w, w0.shape[1], 64, 3, 3, 1, 1, PAD_ZERO)
+    d1 = ConvDesc(_dt(img), n, h, w, 64, 64, 3, 3, 2, 1, PAD_ZERO)
+    return bool(_lib.lib().dsr_conv_first2_supported(C.byref(d0), C.byref(d1)))
+
+
 def _out_hw(desc):
     oh, ow = C.c_int(), C.c_int()
     check(_lib.lib().dsr_conv_out_size(C.byref(desc), C.byref(oh), C.byref(ow)))
@@ -451,8 +462,11 @@ class ConvAct(torch.autograd.Function):
             y = torch.empty((n, oh, ow, r8(cout)), dtype=x.dtype, device=x.device)
         act = cfg.get("act", ACT_NONE)
         ep = Epilogue(act, float(cfg.get("slope", 0.0)), _ptr(prelu), _ptr(bias), None, int(ps), None)
-        check(_timed("fwd", desc, lambda: _lib.lib().dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y),
-                                                                    _stream()), ep))
+        if not cfg.get("defer", False):
+            check(_timed("fwd", desc, lambda: _lib.lib().dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y),
+                                                                        _stream()), ep))
+        # (defer: nothing is launched here -- the layer that consumes y computes this layer inside its own forward kernel and
+        #  fills y only if a backward pass will need it: ConvBNAct with cfg["first2"], the discriminator's first two layers)
         ctx.desc, ctx.cfg, ctx.ps, ctx.act = desc, cfg, ps, act
         ctx.wshape = tuple(weight.shape)
         ctx.weight_ref = weight
@@ -565,12 +579,27 @@ class ConvBNAct(torch.autograd.Function):
         mean = torch.empty(cp, dtype=torch.float32, device=dev)
         rstd = torch.empty(cp, dtype=torch.float32, device=dev)
         count = n * oh * ow
-        if train:
+        first2 = cfg.get("first2") if train else None
+        if first2 is not None:
+            # x is the (not yet computed) output of the image layer in front of this one: both convolutions run in ONE kernel
+            # that recomputes that activation per tile in LDS (dsr_conv_first2_fwd) and writes it to x only when a backward
+            # pass will read it (this layer's weight gradient); the forward itself never reads it back from HBM
+            img, w0, b0, slope0 = first2
+            d0 = make_desc(img, w0.shape[0], 3, 3, 1, 1, PAD_ZERO, w0.shape[1])
+            wf0, _ = packed_weights(w0, d0, x.dtype)
+            rows = lib.dsr_conv_first2_stats_rows(C.byref(d0))
+            part = torch.empty((rows + _scr()) * 2 * cp, dtype=torch.float32, device=dev)
+            keep = not cfg.get("infer", False)
+            check(_timed("fwd", desc, lambda: lib.dsr_conv_first2_fwd(
+                C.byref(d0), C.byref(desc), _ptr(img), _ptr(wf0), _ptr(b0.detach() if b0 is not None else None), float(slope0),
+                _ptr(wf), _ptr(bias), _ptr(x) if keep else None, _ptr(y), _ptr(part), _stream()), name="conv_first2_kernel"))
+        elif train:
             rows = lib.dsr_conv_stats_rows(C.byref(desc))
             part = torch.empty((rows + _scr()) * 2 * cp, dtype=torch.float32, device=dev)
             ep = Epilogue(ACT_NONE, 0.0, None, _ptr(bias), _ptr(part), 0, None)
             check(_timed("fwd", desc, lambda: lib.dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), _ptr(y),
                                                                  _stream()), ep))
+        if train:
             check(lib.dsr_pw_bn_finalize(_ptr(part), rows, cp, cout, cp, float(count), _ptr(gamma), _ptr(beta),
                                          _ptr(running_mean), _ptr(running_var), _ptr(nbt), BN_MOMENTUM, BN_EPS,
                                          int(cfg.get("bn_updates", 1)),

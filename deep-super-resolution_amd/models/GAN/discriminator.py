@@ -21,8 +21,10 @@ class DiscriminatorConvBlock(nn.Module):
         self.stride = stride
         self.compute_dtype = torch.bfloat16
 
-    def _block(self, x):
+    def _block(self, x, first2=None):
         cfg = dict(stride=self.stride, pad=1, act=F.ACT_LEAKY, slope=0.2, train=self.training)
+        if first2 is not None:
+            cfg["first2"] = first2
         return F.ConvBNAct.apply(x, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias,
                                  self.bn1.running_mean, self.bn1.running_var, self.bn1.num_batches_tracked,
                                  None, None, cfg)                                           # discriminator.py:15-17
@@ -64,10 +66,14 @@ class Discriminator(nn.Module):
     def features(self, x):
         """conv stack (:60-63) -> NHWC 16-bit [N, H/16, W/16, 512]"""
         xi = F.ToNHWC.apply(x, self.compute_dtype)
+        blk0 = self.convblocks[0]
+        fused = blk0.training and F.first2_supported(xi, self.conv.weight, blk0.conv1.weight, blk0.stride)
+        # fused: the first layer is computed INSIDE the second layer's forward kernel (its 64-channel activation, 1.07 GB at
+        # 512x512 x 32, is recomputed per tile and written only for a backward pass); ConvAct then only allocates and records
         z = F.ConvAct.apply(xi, self.conv.weight, self.conv.bias, None,
-                            dict(stride=1, pad=1, act=F.ACT_LEAKY, slope=0.2))            # :60-61
-        for blk in self.convblocks:                                                           # :63
-            z = blk._block(z)
+                            dict(stride=1, pad=1, act=F.ACT_LEAKY, slope=0.2, defer=fused))  # :60-61
+        for i, blk in enumerate(self.convblocks):                                             # :63
+            z = blk._block(z, (xi, self.conv.weight, self.conv.bias, 0.2) if (fused and i == 0) else None)
         return z
 
     def head(self, z):

@@ -107,6 +107,16 @@ int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const void* dout, 
 int dsr_conv_first_bwd_recompute(const dsr_conv_desc* d, const void* x, const void* dout, const float* w, const float* bias,
                                  int act, float slope, float* dw, float* db, void* workspace, size_t ws_bytes, dsr_stream_t s);
 
+/* The discriminator's first two convolutions (discriminator.py:25 Conv2d(3,64,3,1,1) + LeakyReLU; :29 Conv2d(64,64,3,2,1) in
+ * front of its BatchNorm) as ONE forward launch: the first layer's 64-channel activation (1.07 GB at 512x512, batch 32) is
+ * recomputed per tile in LDS and goes to HBM only if `a0` is given (training: the second layer's weight gradient reads it).
+ * d0 / d1: the two layers' descriptors (same N, H, W); x: NHWC 16-bit image with 8 channels; w0 / w1: packed forward images;
+ * y1: raw second-layer output [N][OH][OW][64]; stats (nullable): dsr_conv_first2_stats_rows(d0) rows of [2][64] partial sums. */
+int dsr_conv_first2_supported(const dsr_conv_desc* d0, const dsr_conv_desc* d1);
+int dsr_conv_first2_stats_rows(const dsr_conv_desc* d0);
+int dsr_conv_first2_fwd(const dsr_conv_desc* d0, const dsr_conv_desc* d1, const void* x, const void* w0, const float* bias0,
+                        float slope0, const void* w1, const float* bias1, void* a0, void* y1, float* stats, dsr_stream_t s);
+
 /* Which kernel the dispatcher launches for this descriptor (measurement aid: bench.py labels its HIP-event timings
  * with it so they can be matched against rocprofv3's kernel names).  op: 0 forward, 1 dgrad, 2 wgrad.  `e` may be
  * NULL (no statistics, no pixel shuffle, NHWC output).  Returns a static string; never NULL. */

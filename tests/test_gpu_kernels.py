@@ -482,6 +482,67 @@ def test_first_layer_fused_backward(dev, n, h, w, actn):
     assert rel_err(dw_f, dw_u) < 5e-3 and rel_err(db_f, db_u) < 5e-3
 
 
+@pytest.mark.parametrize("n,h,w,keep", [(2, 64, 64, True), (3, 37, 70, True), (1, 128, 200, False), (33, 16, 128, True)])
+def test_first_two_layers_fused_forward(dev, n, h, w, keep):
+    """dsr_conv_first2_fwd -- discriminator.py:25 (Conv2d(3,64,3,1,1) + LeakyReLU(0.2)) and :29 (Conv2d(64,64,3,2,1) in front of its
+    BatchNorm) as one launch, the first layer's activation recomputed per tile in LDS -- against the two launches it replaces
+    (dsr_conv_fwd twice: the first-layer kernel walks K in the same order, so a0 must agree BIT FOR BIT; the second layer sums
+    the same products with its bias added first instead of last) and against plain fp32 PyTorch on the same bf16 operands:
+    a0, y1 and the BatchNorm sum / sum of squares of the reference's y1.  Odd sizes (ragged tiles, odd image height: the last
+    output row reads one a0 row past... none: zero padding), more tiles than persistent blocks, and a0 = NULL (inference)."""
+    import ctypes as C
+    L = P("_lib")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cpu").manual_seed(13)
+    x = bfr(torch.rand(n, 3, h, w, generator=g) * 2 - 1)
+    w0 = bfr((torch.rand(64, 3, 3, 3, generator=g) - 0.5) * 0.6)
+    b0 = (torch.rand(64, generator=g) - 0.5) * 0.2
+    w1 = bfr((torch.rand(64, 64, 3, 3, generator=g) - 0.5) * 0.1)
+    b1 = (torch.rand(64, generator=g) - 0.5) * 0.2
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    d0 = L.ConvDesc(L.BF16, n, h, w, 3, 64, 3, 3, 1, 1, 0)
+    d1 = L.ConvDesc(L.BF16, n, h, w, 64, 64, 3, 3, 2, 1, 0)
+    assert lib.dsr_conv_first2_supported(C.byref(d0), C.byref(d1)) == 1
+
+    def pack(d, wt):
+        wf = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 0), dtype=torch.bfloat16, device=dev)
+        wd = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 1), dtype=torch.bfloat16, device=dev)
+        L.check(lib.dsr_conv_pack_weight(C.byref(d), wt.to(dev).data_ptr(), wf.data_ptr(), wd.data_ptr(), st))
+        return wf
+    wf0, wf1 = pack(d0, w0), pack(d1, w1)
+    xg = to_nhwc(x).to(dev)
+    b0g, b1g = b0.to(dev), b1.to(dev)
+    # ---- two launches
+    a0_two = torch.full((n, h, w, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    ep0 = L.Epilogue(L.ACT_LEAKY, 0.2, None, b0g.data_ptr(), None, 0, None)
+    L.check(lib.dsr_conv_fwd(C.byref(d0), xg.data_ptr(), wf0.data_ptr(), C.byref(ep0), a0_two.data_ptr(), st))
+    y1_two = torch.full((n, oh, ow, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    ep1 = L.Epilogue(L.ACT_NONE, 0.0, None, b1g.data_ptr(), None, 0, None)
+    L.check(lib.dsr_conv_fwd(C.byref(d1), a0_two.data_ptr(), wf1.data_ptr(), C.byref(ep1), y1_two.data_ptr(), st))
+    # ---- one launch
+    rows = lib.dsr_conv_first2_stats_rows(C.byref(d0))
+    assert 0 < rows <= 256
+    a0 = torch.full((n, h, w, 64), float("nan"), dtype=torch.bfloat16, device=dev) if keep else None
+    y1 = torch.full((n, oh, ow, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    part = torch.full((rows, 2, 64), float("nan"), dtype=torch.float32, device=dev)
+    L.check(lib.dsr_conv_first2_fwd(C.byref(d0), C.byref(d1), xg.data_ptr(), wf0.data_ptr(), b0g.data_ptr(), 0.2, wf1.data_ptr(),
+                                    b1g.data_ptr(), a0.data_ptr() if keep else None, y1.data_ptr(), part.data_ptr(), st))
+    torch.cuda.synchronize()
+    if keep:
+        assert torch.equal(a0, a0_two)
+    assert torch.isfinite(y1.float()).all() and torch.isfinite(part).all()
+    assert rel_err(y1.float(), y1_two.float()) <= 2.0 ** -7
+    # ---- fp32 reference
+    a0_r = bfr(TF.leaky_relu(TF.conv2d(x, w0, b0, padding=1), 0.2))
+    y1_r = TF.conv2d(a0_r, w1, b1, stride=2, padding=1)
+    assert rel_err(from_nhwc(a0_two.cpu(), 64), a0_r) <= 1.2e-2
+    assert rel_err(from_nhwc(y1.cpu(), 64), y1_r) <= 1.2e-2
+    st_ref = torch.stack([y1_r.double().sum((0, 2, 3)), (y1_r.double() ** 2).sum((0, 2, 3))])
+    got = part.double().sum(0).cpu()
+    assert float((got - st_ref).abs().max() / st_ref.abs().max()) < 2e-3
+
+
 @pytest.mark.parametrize("b,hw,c,cp,bp", [(5, 72, 100, 128, 8), (64, 1024, 512, 512, 64), (3, 8, 64, 64, 16)])
 def test_flatten_tile_kernel_equals_strided_form(dev, b, hw, c, cp, bp):
     """dsr_flatten (NHWC <-> the CHW-flattened operand of the dense head, discriminator.py:37-39,60-62) has a tile form that
