@@ -7,9 +7,12 @@ mkdir -p $O
 cd $R
 timeout -k 10 400 python3 bench.py > $O/bench_gan_x4.json 2> $O/bench_gan_x4.err
 echo "bench done"; tail -n 3 $O/bench_gan_x4.err
-for w in gen_l1_x4 infer_x8 dip_x2; do timeout -k 10 200 python3 bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; tail -n 1 $O/bench_$w.err; done
+for w in gen_l1_x4 infer_x8 dip_x2; do timeout -k 10 200 python3 bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; tail -n 1 $O/bench_$w.err; done
 timeout -k 10 300 python3 tools/microbench_conv.py > $O/microbench_conv.txt 2>&1
 timeout -k 10 100 python3 tools/microbench_dense_adam.py > $O/microbench_dense_adam.txt 2>&1
+timeout -k 10 100 python3 tools/microbench_first2.py > $O/microbench_first2.txt 2>&1
+timeout -k 10 100 python3 tools/microbench_first_bwd.py > $O/microbench_first_bwd.txt 2>&1
+timeout -k 10 100 python3 tools/trace_step.py > $O/trace_step.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 DSR_GAN_OVERLAP=0 DSR_GAN_GRAPH=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -o ser -- python3 $R/bench.py --steps 7 --warmup 2 --no-cpu-baseline --no-psnr --no-roofline --no-other-workloads > $O/prof_ser.log 2>&1
 echo "prof serial done"
