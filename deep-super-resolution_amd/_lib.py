@@ -78,9 +78,6 @@ SIGNATURES = {
     "dsr_pw_channel_stats": (_I, [_I, _P, _Z, _I, _I, _I, _P, _P]),
     "dsr_pw_bn_act_fwd": (_I, [_I, _P, _P, _P, _P, _P, _Z, _I, _I, _F, _P, _P]),
     "dsr_pw_bn_act_bwd_reduce": (_I, [_I, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _F, _P, _P, _P]),
-    "dsr_pw_bn_bwd_fused_workspace": (_Z, [_I, _I]),
-    "dsr_pw_bn_bwd_fused_counters": (_I, []),
-    "dsr_pw_bn_act_bwd_reduce_final": (_I, [_I, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _F, _P, _F, _P, _Z, _P, _P, _P, _P, _P, _P, _P]),
     "dsr_pw_bn_bwd_finalize": (_I, [_P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dsr_pw_bn_act_bwd_apply": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _F, _P, _I, _P]),
     "dsr_pw_act_bwd": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P]),
@@ -128,7 +125,7 @@ _lib = None
 LAUNCH_LOG = None
 _NO_LAUNCH = ("dsr_last_error", "dsr_abi_version", "dsr_conv_kernel_name", "dsr_conv_wgrad_batchable", "dsr_conv_wgrad_batched_workspace", "dsr_conv_dgrad_add_supported", "dsr_conv_dgrad_masked_supported", "dsr_conv_fwd_affine_supported",
               "dsr_conv_first2_supported", "dsr_conv_first2_stats_rows", "dsr_conv_first_bwd_supported", "dsr_conv_first_bwd_workspace", "dsr_conv_out_size", "dsr_conv_stats_rows",
-              "dsr_conv_packed_elems", "dsr_conv_dgrad_workspace", "dsr_conv_wgrad_workspace", "dsr_pw_scratch_rows", "dsr_pw_bn_bwd_fused_workspace", "dsr_pw_bn_bwd_fused_counters",
+              "dsr_conv_packed_elems", "dsr_conv_dgrad_workspace", "dsr_conv_wgrad_workspace", "dsr_pw_scratch_rows",
               "dsr_pw_reduce_blocks", "dsr_linear_fwd_workspace", "dsr_ssim_blocks")
 
 

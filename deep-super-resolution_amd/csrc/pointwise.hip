@@ -545,33 +545,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const unsigned short* _
 // pass 1: per-channel partial sums of g, g*xhat and the PReLU slope gradient sum(dout * z * [z<0]).
 // WITH_P: the launch also forms the PReLU slope gradient (8 more accumulators).  The per-channel scale / shift live in LDS (read
 // per row pair) rather than in 16 registers: with both, the two-rows-in-flight form fits 5 waves per SIMD instead of 4.
-// Fused finalize (dsr_pw_bn_act_bwd_reduce_final): the partial rows are folded INSIDE this launch by a two-level "last block"
-// scheme instead of by a compaction launch + a finalize launch (2 x ~5 us + two kernel boundaries per BatchNorm layer, 47 layers
-// per config-3 step, a third of config 2's launches).  Blocks form groups of DSR_BWD_GROUP; every block publishes its row with
-// write-through stores and bumps its group's counter; the block whose bump completes the group sums the group's rows IN ROW
-// ORDER into one double-precision group row and bumps the launch counter; the block that completes THAT sums the group rows in
-// order and writes dgamma / dbeta / dprelu / c1 / c2.  Which block does the summing depends on timing, what it sums and in which
-// order does not: deterministic.  The counters live in a caller-owned, zero-initialised, per-stream buffer and are reset by the
-// last block (launches of one stream are ordered, so one set per stream is enough).
-#define DSR_BWD_GROUP 32
-#define DSR_BWD_CSTRIDE 64     // counter words are 256 bytes apart: 1,280 device-scope atomics on one or two cache lines serialise
-                               // (~12 ns each, MI355X_MICROARCH.md "fanin"): 15 us per launch, measured
-struct BnBwdFinal {
-  unsigned* counters;    // [1 + groups]; null: no fused finalize
-  double* group_rows;    // [groups][3][Cp]
-  float* dgamma;
-  float* dbeta;
-  float* dprelu;
-  float* c1;
-  float* c2;
-  int C;
-  float count;
-};
 template <int DT, bool NT, int UNR, bool WITH_P>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     const unsigned short* __restrict__ dout, const unsigned short* __restrict__ y, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd, size_t P, int Cp,
-    int rows_per_block, int act, float slope_v, const float* __restrict__ prelu, float* __restrict__ partial, const BnBwdFinal fin) {
+    int rows_per_block, int act, float slope_v, const float* __restrict__ prelu, float* __restrict__ partial) {
   __shared__ float red[256 * 24];
   const int cpr = Cp / 8;
   const int tid = threadIdx.x;
@@ -640,119 +618,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     red[tid * 24 + 16 + k] = WITH_P ? sp[k] : 0.f;
   }
   __syncthreads();
-  if (!fin.counters) {
-    for (int c = tid; c < 3 * Cp; c += 256) {
-      int which = c / Cp, cc = c % Cp;
-      int chn = cc / 8, k = cc % 8;
-      float s = 0.f;
-      for (int r = 0; r < rpi; ++r) s += red[(r * cpr + chn) * 24 + which * 8 + k];
-      partial[((size_t)blockIdx.x * 3 + which) * Cp + cc] = s;
-    }
-    return;
-  }
-  // fused finalize: the same sums, four columns per thread, published with ONE write-through 16-byte store each (the row must be
-  // visible to a block on another XCD: MI355X_MICROARCH.md, R1 hand-off; a 4-byte write-through store costs a fabric write of its own)
-  for (int c4 = tid; c4 < 3 * Cp / 4; c4 += 256) {
-    const int c = 4 * c4, which = c / Cp, cc = c % Cp;
-    const int chn = cc / 8, k = cc % 8;                    // (k = 0 or 4: the four columns are one 8-channel chunk's half)
-    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < rpi; ++r) {
-      const float* src = &red[(r * cpr + chn) * 24 + which * 8 + k];
-      s[0] += src[0];
-      s[1] += src[1];
-      s[2] += src[2];
-      s[3] += src[3];
-    }
-    float* dst = &partial[(size_t)blockIdx.x * 3 * Cp + c];
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(s) : "memory");
-  }
-  // ---- fused finalize, level 1: the block that completes its group folds the group's rows
-  __shared__ int s_last;
-  const int nblk = (int)gridDim.x, ngroups = (nblk + DSR_BWD_GROUP - 1) / DSR_BWD_GROUP;
-  const int grp = (int)blockIdx.x / DSR_BWD_GROUP;
-  const int b0 = grp * DSR_BWD_GROUP, b1 = b0 + DSR_BWD_GROUP < nblk ? b0 + DSR_BWD_GROUP : nblk;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's row stores are done ...
-  __syncthreads();                                        // ... before the one lane signals for all of them
-  if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(fin.counters + (1 + grp) * DSR_BWD_CSTRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = old == (unsigned)(b1 - b0 - 1);
-    if (s_last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  __syncthreads();
-  if (!s_last) return;
-  // (plain 16-byte loads behind the acquire + barrier above, eight rows in flight: one write-through-bypassing load per value
-  //  and row put 32 dependent fabric round trips into this tail -- the fused launch then measured SLOWER than three launches)
-  for (int c4 = tid; c4 < 3 * Cp / 4; c4 += 256) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int b = b0;
-    for (; b + 8 <= b1; b += 8) {
-      f32x4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(&partial[(size_t)(b + u) * 3 * Cp + 4 * c4]);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        s0 += (double)v[u][0];
-        s1 += (double)v[u][1];
-        s2 += (double)v[u][2];
-        s3 += (double)v[u][3];
-      }
-    }
-    for (; b < b1; ++b) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(&partial[(size_t)b * 3 * Cp + 4 * c4]);
-      s0 += (double)v[0];
-      s1 += (double)v[1];
-      s2 += (double)v[2];
-      s3 += (double)v[3];
-    }
-    double* gr = &fin.group_rows[(size_t)grp * 3 * Cp + 4 * c4];
-    __hip_atomic_store(gr + 0, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(gr + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(gr + 2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(gr + 3, s3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // ---- level 2: the block that completes the launch folds the group rows and finalizes
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(fin.counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = old == (unsigned)(ngroups - 1);
-    if (s_last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  __syncthreads();
-  if (!s_last) return;
-  double* dsum = reinterpret_cast<double*>(red);          // per-channel PReLU terms for the channel sum (Cp <= 2048: 16 KB of the 24 KB)
-  for (int c = tid; c < Cp; c += 256) {
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-    for (int q = 0; q < ngroups; ++q) {                   // fixed order: deterministic (plain loads behind the acquire + barrier)
-      t0 += fin.group_rows[((size_t)q * 3 + 0) * Cp + c];
-      t1 += fin.group_rows[((size_t)q * 3 + 1) * Cp + c];
-      t2 += fin.group_rows[((size_t)q * 3 + 2) * Cp + c];
-    }
-    const bool real = c < fin.C;
-    if (real) t1 = (double)rstd[c] * (t1 - (double)mean[c] * t0);      // sum g*y -> sum g*xhat (as bn_bwd_finalize_par_kernel)
-    if (real) {
-      if (fin.dgamma) fin.dgamma[c] = (float)t1;
-      if (fin.dbeta) fin.dbeta[c] = (float)t0;
-    }
-    fin.c1[c] = real ? (float)(t0 / fin.count) : 0.f;
-    fin.c2[c] = real ? (float)(t1 / fin.count) : 0.f;
-    dsum[c] = real ? t2 : 0.0;
-  }
-  for (int q = tid; q <= ngroups; q += 256)                            // clean for the next launch on this stream
-    __hip_atomic_store(fin.counters + q * DSR_BWD_CSTRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (fin.dprelu) {
-    __syncthreads();
-    if (tid == 0) {
-      double s = 0.0;
-      for (int c = 0; c < fin.C; ++c) s += dsum[c];
-      fin.dprelu[0] = (float)s;
-    }
+  for (int c = tid; c < 3 * Cp; c += 256) {
+    int which = c / Cp, cc = c % Cp;
+    int chn = cc / 8, k = cc % 8;
+    float s = 0.f;
+    for (int r = 0; r < rpi; ++r) s += red[(r * cpr + chn) * 24 + which * 8 + k];
+    partial[((size_t)blockIdx.x * 3 + which) * Cp + cc] = s;
   }
 }
 
@@ -1304,16 +1175,16 @@ extern "C" int dsr_pw_bn_act_fwd(int dtype, const void* y, const float* scale, c
   }
   return dsr_launch_status("dsr_pw_bn_act_fwd");
 }
-static int bn_act_bwd_reduce_impl(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
-                                  const float* mean, const float* rstd, size_t P, int Cp, int blocks, int rpb, int act,
-                                  float slope, const float* prelu, float* partial, const BnBwdFinal& fin, hipStream_t st) {
+extern "C" int dsr_pw_bn_act_bwd_reduce(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
+                              const float* mean, const float* rstd, size_t P, int Cp, int blocks, int rpb, int act,
+                              float slope, const float* prelu, float* partial, hipStream_t st) {
   DSR_REQUIRE(dout && y && scale && shift && mean && rstd && partial && DSR_DTYPE_OK(dtype) && P > 0 && DSR_CP_OK(Cp) && blocks > 0 && rpb > 0, "bn_act_bwd_reduce: null pointer or bad shape");
   DSR_REQUIRE(act != DSR_ACT_PRELU || prelu, "bn_act_bwd_reduce: PReLU needs its weight pointer");
   static const int unr = [] { const char* e = getenv("DSR_PW_REDUCE_UNROLL"); return e ? atoi(e) : 2; }();
 #define LAUNCH_RED2(NTV, U, WP)                                                                                             \
   DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DT, NTV, U, WP>), dim3(blocks), dim3(256), 0, st,           \
                                       (const unsigned short*)dout, (const unsigned short*)y, scale, shift, mean, rstd, P, \
-                                      Cp, rpb, act, slope, prelu, partial, fin))
+                                      Cp, rpb, act, slope, prelu, partial))
 #define LAUNCH_RED(NTV, U)                              \
   do {                                                  \
     if (act == DSR_ACT_PRELU) { LAUNCH_RED2(NTV, U, true); } else { LAUNCH_RED2(NTV, U, false); } \
@@ -1326,43 +1197,6 @@ static int bn_act_bwd_reduce_impl(int dtype, const void* dout, const void* y, co
 #undef LAUNCH_RED
 #undef LAUNCH_RED2
   return dsr_launch_status("dsr_pw_bn_act_bwd_reduce");
-}
-extern "C" int dsr_pw_bn_act_bwd_reduce(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
-                              const float* mean, const float* rstd, size_t P, int Cp, int blocks, int rpb, int act,
-                              float slope, const float* prelu, float* partial, hipStream_t st) {
-  BnBwdFinal fin = BnBwdFinal{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f};
-  return bn_act_bwd_reduce_impl(dtype, dout, y, scale, shift, mean, rstd, P, Cp, blocks, rpb, act, slope, prelu, partial, fin, st);
-}
-// The reduction AND its finalize in one launch (see BnBwdFinal above).  `workspace`: dsr_pw_bn_bwd_fused_workspace(blocks, Cp)
-// bytes (partial rows + double-precision group rows); `counters`: DSR_BWD_COUNTERS zero-initialised 32-bit words owned by the
-// caller, one buffer per stream, left zero by the launch.
-extern "C" size_t dsr_pw_bn_bwd_fused_workspace(int blocks, int Cp) {
-  if (blocks <= 0 || Cp <= 0) return 0;
-  const size_t groups = (size_t)(blocks + DSR_BWD_GROUP - 1) / DSR_BWD_GROUP;
-  return ((size_t)blocks * 3 * Cp * sizeof(float) + 15) / 16 * 16 + groups * 3 * Cp * sizeof(double);
-}
-extern "C" int dsr_pw_bn_bwd_fused_counters(void) { return (1 + 2048 / DSR_BWD_GROUP) * DSR_BWD_CSTRIDE; }
-extern "C" int dsr_pw_bn_act_bwd_reduce_final(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
-                                              const float* mean, const float* rstd, size_t P, int Cp, int C, int blocks, int rpb,
-                                              int act, float slope, const float* prelu, float count, void* workspace,
-                                              size_t ws_bytes, unsigned* counters, float* dgamma, float* dbeta, float* dprelu,
-                                              float* c1, float* c2, hipStream_t st) {
-  DSR_REQUIRE(workspace && counters && c1 && c2 && C > 0 && C <= Cp && count > 0.f && blocks > 0 && blocks <= 2048,
-              "bn_act_bwd_reduce_final: null pointer or bad shape");
-  DSR_REQUIRE(!dprelu || act == DSR_ACT_PRELU, "bn_act_bwd_reduce_final: a PReLU slope gradient needs the PReLU reduction");
-  if (ws_bytes < dsr_pw_bn_bwd_fused_workspace(blocks, Cp)) return dsr_fail(DSR_E_WORKSPACE, "bn_act_bwd_reduce_final: workspace %zu < %zu", ws_bytes, dsr_pw_bn_bwd_fused_workspace(blocks, Cp));
-  BnBwdFinal fin;
-  fin.counters = counters;
-  fin.group_rows = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(workspace) + ((size_t)blocks * 3 * Cp * sizeof(float) + 15) / 16 * 16);
-  fin.dgamma = dgamma;
-  fin.dbeta = dbeta;
-  fin.dprelu = dprelu;
-  fin.c1 = c1;
-  fin.c2 = c2;
-  fin.C = C;
-  fin.count = count;
-  return bn_act_bwd_reduce_impl(dtype, dout, y, scale, shift, mean, rstd, P, Cp, blocks, rpb, act, slope, prelu,
-                                reinterpret_cast<float*>(workspace), fin, st);
 }
 extern "C" int dsr_pw_bn_bwd_finalize(const float* partial, int blocks, int C, int Cp, float count, const float* mean,
                             const float* rstd, float* dgamma, float* dbeta, float* dprelu, float* c1, float* c2,

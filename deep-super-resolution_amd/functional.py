@@ -195,40 +195,6 @@ def _bn_bwd_blocks(p, act):
     return -(-p // rpb), rpb
 
 
-BN_BWD_FUSED = os.environ.get("DSR_BN_BWD_FUSED", "1") != "0"    # 0: reduction + compaction + finalize as separate launches
-_bwd_counters = {}        # (device index, stream handle) -> zero-initialised counters of the fused BatchNorm-backward reduction
-
-
-def _bn_bwd_counters():
-    """The per-stream counter words of dsr_pw_bn_act_bwd_reduce_final (zeroed once; the launch leaves them zero)."""
-    st = torch.cuda.current_stream()
-    key = (st.device.index, st.cuda_stream)
-    buf = _bwd_counters.get(key)
-    if buf is None:
-        buf = _bwd_counters[key] = torch.zeros(_lib.lib().dsr_pw_bn_bwd_fused_counters(), dtype=torch.int32, device=st.device)
-    return buf
-
-
-def _bn_bwd_reduce(x, dout, y, scale, shift, mean, rstd, p, cp, c, act, slope, prelu, dgamma, dbeta, dprelu, c1, c2):
-    """Per-channel sums of the BatchNorm + activation backward and their finalize (dgamma, dbeta, dprelu, c1, c2): one launch
-    (dsr_pw_bn_act_bwd_reduce_final) or, with BN_BWD_FUSED off, reduction + compaction + finalize."""
-    lib = _lib.lib()
-    blocks, rpb = _bn_bwd_blocks(p, act)
-    if BN_BWD_FUSED and blocks <= 2048:
-        wsz = lib.dsr_pw_bn_bwd_fused_workspace(blocks, cp)
-        ws = torch.empty(wsz, dtype=torch.uint8, device=x.device)
-        check(lib.dsr_pw_bn_act_bwd_reduce_final(_dt(x), _ptr(dout), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), p, cp,
-                                                 c, blocks, rpb, act, slope, _ptr(prelu), float(p), _ptr(ws), wsz,
-                                                 _ptr(_bn_bwd_counters()), _ptr(dgamma), _ptr(dbeta), _ptr(dprelu), _ptr(c1),
-                                                 _ptr(c2), _stream()))
-        return
-    part = torch.empty((blocks + _scr()) * 3 * cp, dtype=torch.float32, device=x.device)
-    check(lib.dsr_pw_bn_act_bwd_reduce(_dt(x), _ptr(dout), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), p, cp, blocks,
-                                       rpb, act, slope, _ptr(prelu), _ptr(part), _stream()))
-    check(lib.dsr_pw_bn_bwd_finalize(_ptr(part), blocks, c, cp, float(p), _ptr(mean), _ptr(rstd), _ptr(dgamma), _ptr(dbeta),
-                                     _ptr(dprelu), _ptr(c1), _ptr(c2), _stream()))
-
-
 _wgrad_batch = None      # the open batched_wgrad context (per process: backward passes are issued from one thread here)
 
 
@@ -711,7 +677,13 @@ class ConvBNAct(torch.autograd.Function):
         dgamma = torch.empty(cout, dtype=torch.float32, device=dev)
         dbeta = torch.empty(cout, dtype=torch.float32, device=dev)
         dprelu = torch.empty(1, dtype=torch.float32, device=dev) if prelu is not None else None
-        _bn_bwd_reduce(x, dout, y, scale, shift, mean, rstd, p, cp, cout, ctx.act, slope, prelu, dgamma, dbeta, dprelu, c1, c2)
+        blocks, rpb = _bn_bwd_blocks(p, ctx.act)
+        part = torch.empty((blocks + _scr()) * 3 * cp, dtype=torch.float32, device=dev)
+        check(lib.dsr_pw_bn_act_bwd_reduce(_dt(x), _ptr(dout), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean),
+                                           _ptr(rstd), p, cp, blocks, rpb, ctx.act, slope, _ptr(prelu), _ptr(part),
+                                           _stream()))
+        check(lib.dsr_pw_bn_bwd_finalize(_ptr(part), blocks, cout, cp, float(p), _ptr(mean), _ptr(rstd), _ptr(dgamma),
+                                         _ptr(dbeta), _ptr(dprelu), _ptr(c1), _ptr(c2), _stream()))
         dy = torch.empty_like(y)
         check(lib.dsr_pw_bn_act_bwd_apply(_dt(x), _ptr(dout), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
                                           _ptr(c1), _ptr(c2), _ptr(dy), p, cp, ctx.act, slope, _ptr(prelu),
@@ -1269,7 +1241,12 @@ class BNAct(torch.autograd.Function):
         c2 = torch.empty(cp, dtype=torch.float32, device=dev)
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
-        _bn_bwd_reduce(x, dout, x, scale, shift, mean, rstd, p, cp, c, ctx.act, slope, None, dgamma, dbeta, None, c1, c2)
+        blocks, rpb = _bn_bwd_blocks(p, ctx.act)
+        part = torch.empty((blocks + _scr()) * 3 * cp, dtype=torch.float32, device=dev)
+        check(lib.dsr_pw_bn_act_bwd_reduce(_dt(x), _ptr(dout), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
+                                           p, cp, blocks, rpb, ctx.act, slope, None, _ptr(part), _stream()))
+        check(lib.dsr_pw_bn_bwd_finalize(_ptr(part), blocks, c, cp, float(p), _ptr(mean), _ptr(rstd), _ptr(dgamma),
+                                         _ptr(dbeta), None, _ptr(c1), _ptr(c2), _stream()))
         dx = torch.empty_like(x)
         check(lib.dsr_pw_bn_act_bwd_apply(_dt(x), _ptr(dout), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
                                           _ptr(c1), _ptr(c2), _ptr(dx), p, cp, ctx.act, slope, None, int(ctx.train),

@@ -175,17 +175,6 @@ int dsr_pw_bn_act_bwd_reduce(int dtype, const void* dout, const void* y, const f
 int dsr_pw_bn_bwd_finalize(const float* partial, int blocks, int C, int Cp, float count, const float* mean,
                            const float* rstd, float* dgamma, float* dbeta, float* dprelu, float* c1, float* c2,
                            dsr_stream_t s);
-/* dsr_pw_bn_act_bwd_reduce + dsr_pw_bn_bwd_finalize as ONE launch: the partial rows are folded inside the reduction launch by a
- * two-level "last block" scheme (deterministic: fixed summation order).  workspace: dsr_pw_bn_bwd_fused_workspace(blocks, Cp)
- * bytes; counters: dsr_pw_bn_bwd_fused_counters() 32-bit words, ZERO-INITIALISED ONCE by the caller, one buffer per stream
- * (the launch leaves them zero).  blocks <= 2048. */
-size_t dsr_pw_bn_bwd_fused_workspace(int blocks, int Cp);
-int dsr_pw_bn_bwd_fused_counters(void);
-int dsr_pw_bn_act_bwd_reduce_final(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
-                                   const float* mean, const float* rstd, size_t P, int Cp, int C, int blocks, int rpb, int act,
-                                   float slope, const float* prelu, float count, void* workspace, size_t ws_bytes,
-                                   unsigned* counters, float* dgamma, float* dbeta, float* dprelu, float* c1, float* c2,
-                                   dsr_stream_t s);
 int dsr_pw_bn_act_bwd_apply(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
                             const float* mean, const float* rstd, const float* c1, const float* c2, void* dy, size_t P,
                             int Cp, int act, float slope, const float* prelu, int train, dsr_stream_t s);

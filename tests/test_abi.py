@@ -100,7 +100,6 @@ def test_bad_arguments_return_codes_not_crashes(so):
         lambda: lib.dsr_pw_bn_act_fwd(0, one, one, one, N, one, 64, 64, L.ACT_PRELU, 0.0, N, st),   # PReLU without its weight
         lambda: lib.dsr_pw_bn_act_bwd_reduce(0, N, N, N, N, N, N, 64, 64, 1, 64, 0, 0.0, N, N, st),
         lambda: lib.dsr_pw_bn_bwd_finalize(N, 1, 64, 64, 64.0, N, N, N, N, N, N, N, st),
-        lambda: lib.dsr_pw_bn_act_bwd_reduce_final(0, N, N, N, N, N, N, 64, 64, 64, 1, 64, 0, 0.0, N, 64.0, N, 0, N, N, N, N, N, N, st),
         lambda: lib.dsr_pw_bn_act_bwd_apply(0, N, N, N, N, N, N, N, N, N, 64, 64, 0, 0.0, N, 1, st),
         lambda: lib.dsr_pw_act_bwd(0, N, N, N, 1, 4, 4, 64, 64, 0, 1, 0.2, N, 1, 64, N, st),
         lambda: lib.dsr_pw_act_bwd(0, one, one, one, 1, 4, 4, 64, 64, 0, L.ACT_LEAKY, -0.1, N, 1, 64, N, st),   # slope <= 0

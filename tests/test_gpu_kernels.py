@@ -482,71 +482,6 @@ def test_first_layer_fused_backward(dev, n, h, w, actn):
     assert rel_err(dw_f, dw_u) < 5e-3 and rel_err(db_f, db_u) < 5e-3
 
 
-@pytest.mark.parametrize("p,c,actn", [(1554, 64, "prelu"), (40000, 64, "prelu"), (32768, 128, "leaky"), (150001, 512, "leaky"),
-                                      (70, 8, "none")])
-def test_bn_backward_reduction_with_fused_finalize(dev, p, c, actn):
-    """dsr_pw_bn_act_bwd_reduce_final (the BatchNorm + activation backward sums AND their finalize in one launch: partial rows
-    folded by a two-level last-block scheme inside the reduction kernel) against the three launches it replaces (reduction,
-    compaction, finalize) and against float64 sums on the CPU: dgamma, dbeta, the PReLU slope gradient, c1, c2.  Run twice on
-    the same stream: the counter words must be left clean for the next launch.  1 ... 1280 blocks, ragged last block."""
-    F = P("functional")
-    act = dict(none=F.ACT_NONE, leaky=F.ACT_LEAKY, prelu=F.ACT_PRELU)[actn]
-    cp = (c + 7) // 8 * 8
-    g = torch.Generator(device="cpu").manual_seed(p + c)
-    y = bfr(torch.randn(p, cp, generator=g))
-    dout = bfr(torch.randn(p, cp, generator=g))
-    y[:, c:] = 0
-    dout[:, c:] = 0
-    gamma = torch.rand(c, generator=g) + 0.5
-    beta = torch.rand(c, generator=g) - 0.5
-    mean = y[:, :c].double().mean(0)
-    var = y[:, :c].double().var(0, unbiased=False)
-    rstd = 1.0 / torch.sqrt(var + 1e-5)
-    scale = torch.zeros(cp)
-    shift = torch.zeros(cp)
-    scale[:c] = (gamma.double() * rstd).float()
-    shift[:c] = (beta.double() - mean * gamma.double() * rstd).float()
-    mean_p, rstd_p = torch.zeros(cp), torch.zeros(cp)
-    mean_p[:c], rstd_p[:c] = mean.float(), rstd.float()
-    slope = 0.25
-    prelu = torch.tensor([slope]).to(dev) if act == F.ACT_PRELU else None
-    dev_t = [t.to(dev) for t in (scale, shift, mean_p, rstd_p)]
-    yg, dg = y.to(torch.bfloat16).to(dev), dout.to(torch.bfloat16).to(dev)
-    res = {}
-    try:
-        for fused in (True, True, False):
-            F.BN_BWD_FUSED = fused
-            outs = [torch.full((n_,), float("nan"), device=dev) for n_ in (c, c, 1, cp, cp)]
-            F._bn_bwd_reduce(yg, dg, yg, *dev_t, p, cp, c, act, 0.2 if act == F.ACT_LEAKY else slope, prelu, outs[0], outs[1],
-                             outs[2] if prelu is not None else None, outs[3], outs[4])
-            torch.cuda.synchronize()
-            res.setdefault(fused, []).append([o.cpu() for o in outs])
-            if fused:
-                assert int(F._bn_bwd_counters().abs().sum()) == 0
-    finally:
-        F.BN_BWD_FUSED = True
-    (a1, a2), (b,) = res[True], res[False]
-    for u, v in zip(a1, a2):
-        assert torch.equal(u, v) or (torch.isnan(u).all() and torch.isnan(v).all())          # same launch twice: bit for bit
-    # float64 reference
-    z = y[:, :c].double() * scale[:c].double() + shift[:c].double()
-    sl = 0.2 if act == F.ACT_LEAKY else slope
-    dact = torch.ones_like(z) if act == F.ACT_NONE else torch.where(z >= 0, torch.ones_like(z), torch.full_like(z, sl))
-    gg = dout[:, :c].double() * dact
-    xhat = (y[:, :c].double() - mean) * rstd
-    ref = [(gg * xhat).sum(0), gg.sum(0), (dout[:, :c].double() * z * (z < 0)).sum().reshape(1), gg.sum(0) / p, (gg * xhat).sum(0) / p]
-    names = ["dgamma", "dbeta", "dprelu", "c1", "c2"]
-    for i, name in enumerate(names):
-        if name == "dprelu" and prelu is None:
-            continue
-        r = ref[i].float()
-        for tag, got in (("fused", a1[i]), ("separate", b[i])):
-            gsel = got[:r.numel()]
-            assert torch.isfinite(gsel).all(), (tag, name)
-            assert float((gsel.double() - r.double()).abs().max()) <= 2e-4 * float(r.abs().max()) + 1e-5, (tag, name)
-        assert float((a1[i][:r.numel()] - b[i][:r.numel()]).abs().max()) <= 2e-6 * float(r.abs().max()) + 1e-7, name
-
-
 @pytest.mark.parametrize("n,h,w,keep", [(2, 64, 64, True), (3, 37, 70, True), (1, 128, 200, False), (33, 16, 128, True)])
 def test_first_two_layers_fused_forward(dev, n, h, w, keep):
     """dsr_conv_first2_fwd -- discriminator.py:25 (Conv2d(3,64,3,1,1) + LeakyReLU(0.2)) and :29 (Conv2d(64,64,3,2,1) in front of its
