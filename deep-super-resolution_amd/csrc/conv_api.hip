@@ -743,6 +743,7 @@ extern "C" int dsr_conv_wgrad_batched(int count, const dsr_conv_desc* descs, con
 static const char* gemm_name(int nb, long long M = 0, bool fast = false, bool stats = true, int flags = 0) {
   if (nb > 64 && dsr_conv_gemm_use_224(M, nb, fast, flags | (stats ? DSR_F_STATS : 0))) return "conv_gemm_kernel<224x256>";
   if (nb > 64 && dsr_conv_gemm_use_256(M, nb, fast, stats)) return "conv_gemm_kernel<256x256>";
+  if (nb > 64 && dsr_conv_gemm_use_64(M, nb, fast, flags | (stats ? DSR_F_STATS : 0))) return "conv_gemm_kernel<64x128>";
   return nb > 64 ? "conv_gemm_kernel<128x128>" : (nb > 16 ? "conv_gemm_kernel<128x64>" : "conv_gemm_kernel<128x16>");
 }
 extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, const dsr_epilogue* e) {

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 224 * 25
   constexpr int RA = (BM + RPP - 1) / RPP;
   constexpr int RB = (BN + RPP - 1) / RPP;
   static_assert(BM % RPP == 0 || (DMA && BM % 8 == 0), "partial loader pass: LDS-DMA variants only");
-  static_assert(BM % 128 == 0 || BM == 224, "tile heights");
+  static_assert(BM % 128 == 0 || BM == 224 || BM == 64, "tile heights");
   constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128;
   constexpr int LDS_MAIN = NSTAGE * (A_STAGE + B_STAGE);
   constexpr int C_STRIDE = BN * 2 + 16;
@@ -810,6 +810,8 @@ static void dispatch_dt(const ConvGemmArgs& a, hipStream_t st) {
       launch_one<DT, 256, 256, 2, 4>(a, st);
     else if (use_big && big_mode == 1 && fast && big_tiles >= 512)
       launch_one<DT, 256, 128, 4, 2, 3>(a, st);
+    else if (dsr_conv_gemm_use_64(a.M, a.NB, fast && env_on("DSR_CONV_DMA"), a.flags))
+      launch_one<DT, 64, 128, 1, 4>(a, st);        // few 128-row tiles (VGG conv5_x at batch 32: 196 blocks on 256 CUs): twice as many half-height tiles
     else
       launch_one<DT, 128, 128, 2, 2>(a, st);      // (8 waves of 64x32 were tried: LDS-bound, 35 % slower)
   } else if (a.NB > 16)

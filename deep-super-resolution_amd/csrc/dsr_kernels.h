@@ -98,6 +98,17 @@ static inline bool dsr_conv_gemm_use_224(long long M, int NB, bool fast, int fla
   return r224 * 7 < r256 * 8;
 }
 
+// 64x128 tile (4 waves of 64x32): launches whose 128x128 tiles do not even give every CU one block (VGG conv5_x at batch 32:
+// M = 6,272 -> 49 x 4 = 196 blocks).  Without statistics only (a statistics row covers 128 tile rows).
+// DSR_CONV_BM64: 0 = never, 1 (default) = fewer than 256 tiles of 128x128, 2 = every launch the 128x128 tile would take (tests).
+static inline bool dsr_conv_gemm_use_64(long long M, int NB, bool fast, int flags) {
+  const char* e = getenv("DSR_CONV_BM64");
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0 || !fast || NB % 128 != 0 || (flags & (DSR_F_STATS | DSR_F_PIXSHUF | DSR_F_OUT_NCHW_F32))) return false;
+  if (mode == 2) return true;
+  return ((M + 127) / 128) * (NB / 128) < 256;
+}
+
 bool dsr_launch_conv_gemm_persist(const ConvGemmArgs& a, int dtype, hipStream_t st);   // conv_gemm_persist.hip
 
 struct WgradArgs {

@@ -658,15 +658,17 @@ def test_conv_256x256_tile_equals_128x128(dev, op):
     dy = (torch.rand(n, oh, ow, cout, generator=g) - 0.5).to(torch.bfloat16).to(dev)
     bias = (torch.rand(cout, generator=g) - 0.5).to(dev)
     outs, stats = {}, {}
-    keys = ("DSR_CONV_BIG", "DSR_DGRAD_S2", "DSR_CONV_BM224")
+    keys = ("DSR_CONV_BIG", "DSR_DGRAD_S2", "DSR_CONV_BM224", "DSR_CONV_BM64")
     old = {k: os.environ.get(k) for k in keys}
     os.environ["DSR_DGRAD_S2"] = "0"       # this test is about the gather kernel's tiles: keep stride-2 dgrads on it
     try:
         # DSR_CONV_BM224: 0 = never, 1 = where it saves rounds (default), 2 = wherever the 256x256 tile would be taken
-        for mode, big, b224, want in (("t128", "0", "0", "128x128"), ("t256", "2", "0", "256x256"), ("t224", "2", "2", "224x256")):
-            if mode == "t224" and op == "fwd_stats":
-                continue                   # (the 224-row tile carries no statistics epilogue)
-            os.environ["DSR_CONV_BIG"], os.environ["DSR_CONV_BM224"] = big, b224
+        # DSR_CONV_BM64: 0 = never, 1 = launches of fewer than 256 tiles (default), 2 = wherever the 128x128 tile would be taken
+        for mode, big, b224, b64, want in (("t128", "0", "0", "0", "128x128"), ("t256", "2", "0", "0", "256x256"),
+                                           ("t224", "2", "2", "0", "224x256"), ("t64", "0", "0", "2", "64x128")):
+            if mode in ("t224", "t64") and op == "fwd_stats":
+                continue                   # (the 224- and 64-row tiles carry no statistics epilogue)
+            os.environ["DSR_CONV_BIG"], os.environ["DSR_CONV_BM224"], os.environ["DSR_CONV_BM64"] = big, b224, b64
             if op in ("fwd", "fwd_stats"):
                 y = torch.full((n, oh, ow, cout), float("nan"), dtype=torch.bfloat16, device=dev)
                 rows = lib.dsr_conv_stats_rows(C.byref(d))
@@ -699,8 +701,9 @@ def test_conv_256x256_tile_equals_128x128(dev, op):
     torch.cuda.synchronize()
     assert all(torch.isfinite(o.float()).all() for o in outs.values())
     assert torch.equal(outs["t128"], outs["t256"])
-    if "t224" in outs:
-        assert torch.equal(outs["t128"], outs["t224"])
+    for extra in ("t224", "t64"):
+        if extra in outs:
+            assert torch.equal(outs["t128"], outs[extra]), extra
     # ---- against a plain fp32 PyTorch reference of the same op on the same bf16 operands, at THIS shape: one bf16 rounding
     # of the output = 2^-9 relative to the value, stated relative to the tensor's maximum as everywhere in this file
     xr, wr, dyr = x.float().cpu().permute(0, 3, 1, 2), wt.to(torch.bfloat16).float().cpu(), dy.float().cpu().permute(0, 3, 1, 2)
