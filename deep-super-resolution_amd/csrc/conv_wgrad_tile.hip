@@ -362,18 +362,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_batch_kernel(const Wgra
 // Tiles are 1 output row x 32 columns; the halo is 3 rows x 65 pixels at a pitch of 80.  A fragment's pixel slots
 // are 2 apart (q = kh*80 + kw + 2*lp), so the swizzle key is taken from (q >> 1): with an 80-pixel pitch it reduces to
 // (lp + (kw >> 1)) & 7 -- per-lane, two variants -- and 16 consecutive fragment rows still spread over all 8 slots.
-template <int DT>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTileArgs a) {
+// COH = 2 (round 3): 8 waves, the block owns 128 output channels (two 64-channel halves, waves 4..7 the second) of its
+// 64-input-channel block: the X halo -- the big operand: D.b2's input is 537 MB and every 64-channel output block re-reads it
+// -- is fetched once per 128 instead of once per 64 output channels.  One block per CU (acc alone is 144 registers per wave).
+template <int DT, int COH = 1>
+__global__ __launch_bounds__(256 * COH, 2) void conv_wgrad_dma_s2_kernel(const WgradTileArgs a) {
   constexpr int HC = 80, HR = 3, NSLOT = HR * HC;
-  constexpr int XB = NSLOT * 128, YB = 32 * 128, STAGE = XB + YB;
+  constexpr int XB = NSLOT * 128, YB = 32 * 128, STAGE = XB + COH * YB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it (and what derives from it) in SGPRs
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);   // wave-uniform: keep it (and what derives from it) in SGPRs
+  const int hsel = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);          // output-channel half of this wave (0 when COH == 1)
   // (a wave owns all 64 output channels of a 16-input-channel strip, as in conv_wgrad_dma_body: 4 + 9 fragment reads per
   //  tile instead of 2 + 18)
   const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, cc = 4 * (l16 & 3);
   const int pair = blockIdx.x;
-  const int co0 = (pair / a.tiles_ci) * 64, ci0 = (pair % a.tiles_ci) * 64;
+  const int co0 = (pair / a.tiles_ci) * 64 * COH + hsel * 64, ci0 = (pair % a.tiles_ci) * 64;
 
   f32x4 acc[9][4];
 #pragma unroll
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int ch = i * 16 + cc;
-    offA[i] = XB + lp * 128 + (((ch >> 3) ^ (lp & 7)) << 4) + (ch & 7) * 2;
+    offA[i] = XB + hsel * YB + lp * 128 + (((ch >> 3) ^ (lp & 7)) << 4) + (ch & 7) * 2;
   }
 #pragma unroll
   for (int v = 0; v < 2; ++v) {
@@ -435,6 +439,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
       const bool interior = ix0 >= 0 && ix0 + 65 <= a.IW;
 #pragma unroll
       for (int u = 0; u < NX; ++u) {
+        if (COH == 2 && (u & 1) != hsel) continue;   // (the two halves share the halo fetch: even / odd passes)
         if (32 * u + 8 * wave < NSLOT) {             // wave-uniform
           unsigned off = (unsigned)(xpart[u] + xs);
           if (!interior) {
@@ -444,11 +449,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
           lds_dma16(xr, dx + 32 * u * 128, off);
         }
       }
-      lds_dma16(yr, dx + XB, (ox0 + 32 <= a.OW || ox0 + pb < a.OW) ? (unsigned)(ypart + ys) : OOB);
+      lds_dma16(yr, dx + XB + hsel * YB, (ox0 + 32 <= a.OW || ox0 + pb < a.OW) ? (unsigned)(ypart + ys) : OOB);
       return;
     }
 #pragma unroll
     for (int u = 0; u < (NSLOT + 31) / 32; ++u) {
+      if (COH == 2 && (u & 1) != hsel) continue;
       if (32 * u + 8 * wave < NSLOT) {               // wave-uniform: the last pass only has slots for waves 0 and 1
         const int q = pb + 32 * u;
         const int hr = q / HC, hc = q - hr * HC;
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
     {
       const int ox = ox0 + pb;
       const bool ok = yc_ok && ox < a.OW;
-      lds_dma16(yrsrc, st + XB + 8 * wave * 128, ok ? (unsigned)((((n * a.OH + oy0) * a.OW + ox) * a.CoutP + co0 + ychunk * 8) * 2) : OOB);
+      lds_dma16(yrsrc, st + XB + hsel * YB + 8 * wave * 128, ok ? (unsigned)((((n * a.OH + oy0) * a.OW + ox) * a.CoutP + co0 + ychunk * 8) * 2) : OOB);
     }
   };
 
@@ -528,6 +534,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_s2_kernel(const WgradTi
       }
 }
 
+// stride-2 weight gradient with 128 output channels per (8-wave) block: taken where the re-read of X per output-channel block
+// is what bounds the launch -- D.b2 (537 MB input, two 64-channel blocks): 0.296 -> 0.226 ms; neutral at 268 MB (D.b4), slower
+// at 67 MB (D.b6: 0.169 -> 0.196 ms, one synchronised 8-wave block per CU hides less than two 4-wave blocks), so by input size.
+// DSR_WGRAD_S2_CO128: 0 = never, 1 (default) = inputs of 400 MB or more, 2 = whenever Cout % 128 == 0 (tests).
+static bool dsr_wgrad_s2_co128(int KH, int stride, int CoutP, long long x_bytes) {
+  const char* e = getenv("DSR_WGRAD_S2_CO128");
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0 || KH != 3 || stride != 2 || CoutP < 128 || CoutP % 128 != 0) return false;
+  return mode == 2 || x_bytes >= 400ll * 1000 * 1000;
+}
+
 int dsr_wgrad_tile_plan(int KH, int KW, int stride, int N, int OH, int OW, int CinP, int CoutP, WgradTileArgs* a) {
   const bool k3 = KH == 3 && KW == 3 && (stride == 1 || stride == 2);
   const bool k1 = KH == 1 && KW == 1 && stride == 1;
@@ -536,10 +553,11 @@ int dsr_wgrad_tile_plan(int KH, int KW, int stride, int N, int OH, int OW, int C
   a->tiles_y = (OH + R - 1) / R;
   a->tiles_x = (OW + 31) / 32;
   a->ntiles = N * a->tiles_y * a->tiles_x;
-  a->tiles_co = (CoutP + 63) / 64;
+  const bool co128 = dsr_wgrad_s2_co128(KH, stride, CoutP, (long long)N * (2 * OH) * (2 * OW) * CinP * 2);
+  a->tiles_co = co128 ? CoutP / 128 : (CoutP + 63) / 64;
   a->tiles_ci = (CinP + 63) / 64;
   long long pairs = (long long)a->tiles_co * a->tiles_ci;
-  long long want = (512 + pairs - 1) / pairs;            // 2 resident blocks per CU (VGPR-limited), one wave of blocks
+  long long want = ((co128 ? 256 : 512) + pairs - 1) / pairs;   // 2 resident 4-wave blocks per CU (VGPR-limited) or one 8-wave block, one wave of blocks
   if (want > a->ntiles) want = a->ntiles;
   if (want < 1) want = 1;
   a->tiles_per_block = (int)((a->ntiles + want - 1) / want);
@@ -550,6 +568,8 @@ template <int DT>
 static void launch_dt(const WgradTileArgs& a, int KH, int stride, dim3 grid, hipStream_t st) {
   if (KH == 3 && stride == 1)
     hipLaunchKernelGGL((conv_wgrad_dma_kernel<DT>), grid, dim3(256), 0, st, a);
+  else if (KH == 3 && a.tiles_co * 128 == a.CoutP && a.tiles_co * 64 != a.CoutP)     // (the plan chose 128-channel blocks)
+    hipLaunchKernelGGL((conv_wgrad_dma_s2_kernel<DT, 2>), grid, dim3(512), 0, st, a);
   else if (KH == 3)
     hipLaunchKernelGGL((conv_wgrad_dma_s2_kernel<DT>), grid, dim3(256), 0, st, a);
   else

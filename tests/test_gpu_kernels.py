@@ -879,6 +879,47 @@ def test_conv_wgrad_batched_equals_per_layer_launches(dev):
         assert float((got - per_layer.cpu().double()).abs().max()) < 2e-5 * scale + 1e-4, i
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 40, 48, 64, 128), (1, 33, 70, 128, 256), (3, 16, 16, 192, 384)])
+def test_conv_wgrad_stride2_128_channel_blocks(dev, n, h, w, cin, cout):
+    """conv_wgrad_dma_s2_kernel<COH = 2> (3x3 stride-2 weight gradient with 128 output channels per 8-wave block, so that the
+    input halo is fetched once per 128 instead of once per 64 output channels; discriminator.py:31 at config 3) against the
+    64-channel form (DSR_WGRAD_S2_CO128=0: the same per-wave products, a different pixel partition) and a float64
+    torch.nn.grad.conv2d_weight of the same bf16 operands.  Odd sizes, a ragged last column tile, 192 input channels."""
+    import ctypes as C
+    import os
+    L = P("_lib")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = L.ConvDesc(L.BF16, n, h, w, cin, cout, 3, 3, 2, 1, 0)
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    g = torch.Generator(device="cpu").manual_seed(h * w + cin)
+    x = bfr(torch.rand(n, cin, h, w, generator=g) - 0.5)
+    dy = bfr(torch.rand(n, cout, oh, ow, generator=g) - 0.5)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dy.double(), stride=2, padding=1)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)
+    dyg = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)
+    outs = {}
+    old = os.environ.get("DSR_WGRAD_S2_CO128")
+    try:
+        for mode in ("2", "0"):
+            os.environ["DSR_WGRAD_S2_CO128"] = mode
+            dw = torch.full((cout, cin, 3, 3), float("nan"), dtype=torch.float32, device=dev)
+            wsz = lib.dsr_conv_wgrad_workspace(C.byref(d))
+            ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+            L.check(lib.dsr_conv_wgrad(C.byref(d), xg.data_ptr(), dyg.data_ptr(), dw.data_ptr(), ws.data_ptr(), wsz, st))
+            outs[mode] = dw.cpu().double()
+    finally:
+        if old is None:
+            os.environ.pop("DSR_WGRAD_S2_CO128", None)
+        else:
+            os.environ["DSR_WGRAD_S2_CO128"] = old
+    scale = float(ref.abs().max())
+    for mode, got in outs.items():
+        assert torch.isfinite(got).all(), mode
+        assert float((got - ref).abs().max()) < 2e-5 * scale + 1e-4, mode         # fp32 accumulation of exact bf16 products
+    assert float((outs["2"] - outs["0"]).abs().max()) < 2e-5 * scale + 1e-4
+
+
 def test_conv_wgrad_batched_trunk_sized_group_vs_float64(dev):
     """The grouped weight-gradient launch at the problem COUNT and map sizes of a real backward pass (the generator's
     backward groups 35 problems; here 34: 30 trunk-shaped 64 -> 64 layers on 64x64 maps, a 64 -> 256 PixelShuffle-conv
