@@ -26,7 +26,7 @@ int dsr_launch_status(const char* what) {
   return DSR_OK;
 }
 extern "C" const char* dsr_last_error(void) { return g_err; }
-extern "C" int dsr_abi_version(void) { return 6; }
+extern "C" int dsr_abi_version(void) { return 7; }
 
 static inline int r8(int c) { return (c + 7) & ~7; }
 

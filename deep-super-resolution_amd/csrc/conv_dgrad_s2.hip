@@ -22,6 +22,8 @@
 // in kh,kw inside a class, channel blocks inside a tap) -- tests/test_gpu_kernels.py compares the two bit for bit.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "dsr_common.h"
 #include "dsr_kernels.h"
 
@@ -32,6 +34,15 @@ constexpr int S2_BSLOT = 64 * 128;                // one tap slice: 64 input cha
 constexpr int S2_STAGE = S2_A + 4 * S2_BSLOT;     // 64 KB
 constexpr int S2_CSTRIDE = 64 * 2 + 16;           // C tile row: 64 channels + pad
 constexpr int S2_LDS = 2 * S2_STAGE;
+// FB (the first-layer backward fused into the epilogue, see the kernel): LDS beyond the two stages
+constexpr int FB_IM = 256 * S2_CSTRIDE;           // im2col image [256 pixels][64 B] behind the C tile in the consumed stage
+constexpr int FB_ROW3 = FB_IM + 256 * 64;         // the 4th image halo row, behind it
+constexpr int FB_ROWP = 9 * 1024;                 // halo row pitch: 514 pixels x 16 B arrive as 9 DMA pieces
+constexpr int FB_HALO = S2_LDS;                   // halo rows 0..2: above the two stages
+constexpr int FB_W0 = FB_HALO + 3 * FB_ROWP;      // the first layer's weights [64 co][32 columns] in the storage type
+constexpr int FB_B0 = FB_W0 + 64 * 64;            // its fp32 bias
+constexpr int FB_LDS = FB_B0 + 64 * 4;            // 163,072 of 163,840 bytes
+static_assert(FB_ROW3 + FB_ROWP <= S2_STAGE && FB_LDS <= 160 * 1024, "LDS budget of the fused form");
 
 // class c = 2*ph + pw, shift s = 2*sy + sx: the tap (kh*3 + kw) that shift s feeds into class c, or -1
 __host__ __device__ constexpr int s2_tap(int c, int s) {
@@ -43,7 +54,34 @@ __host__ __device__ constexpr int s2_tap(int c, int s) {
 }
 }   // namespace
 
-template <int DT>
+__device__ __forceinline__ s16x4 s2_tr_read(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+#ifdef DSR_S2_STAMPS
+// Diagnostic build only (tools/diag_dgrad_s2.cpp): per-block cycle sums of {wait for a tile's first DMA, the other waits,
+// MFMA phases, epilogue}, stamped by s_memtime on wave 0; the values go to a buffer nothing else reads.
+__device__ unsigned long long s2_stamps[256][12];
+#define S2_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define S2_ADD(slot, v) st_acc[slot] += (v)
+#else
+#define S2_STAMP(var)
+#define S2_ADD(slot, v)
+#endif
+
+// FB = true (dsr_conv_dgrad_first_bwd: the discriminator's second layer on top of its image layer, discriminator.py:25-29, in
+// a step that needs no image gradient): dx is the gradient of the image layer's activation, 64 channels at full resolution
+// (1.07 GB at 512 x 512 x 32), and its only consumer is that layer's backward -- mask by the activation derivative, bias and
+// weight gradient (conv_first_bwd.hip).  Here the epilogue does that layer's backward on the C tile while it is in LDS and
+// dx is never written: per output-parity class (256 pixels x 64 channels)
+//   * the im2col image B[p][3 tap + ci] of the class's pixels is built from a 4 x 514-pixel image halo (LDS-DMA: rows 0..2
+//     during the tile's second step, row 3 at the top of the epilogue),
+//   * one MFMA per 16 pixels x 16 channels against the image layer's own weights recomputes its pre-activation (fp32), the
+//     accumulators are masked in registers (fp32 product, one rounding) and written to the C tile,
+//   * D[co][col] += sum_p g[p][co] B[p][col] by MFMA with the pixel as contraction index (transposing LDS reads), column 27
+//     of B being 1 (the bias gradient); one partial [64][32] per wave pair and block, folded by first_bwd_finalize_kernel.
+// Only for 64 -> 64 channels (one K block, one channel block) and dY rows that are whole tiles (OW % 256 == 0).
+template <int DT, bool FB>
 __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -55,12 +93,40 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
   const int j = tid & 7, rb = tid >> 3;
   const int jc = j ^ (rb & 7);                       // source-side swizzle (the LDS image of a DMA is lane-linear)
   int a_gy[4], a_gx[4], a_base[4], b_base = 0;
-  const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
+  // (LDS-DMA by inline asm, dsr_common.h: behind the builtin form hipcc puts "s_waitcnt vmcnt(0)" in front of the epilogue's
+  // 8-byte LDS stores, i.e. the next tile's first DMA -- issued so that it flies during the epilogue -- was waited for there)
+  const BufSrd dyr = make_srd(a.dy, a.dy_bytes);
+  const BufSrd wr = make_srd(a.w, a.w_bytes);
   const __amdgpu_buffer_rsrc_t dxr = __builtin_amdgcn_make_buffer_rsrc(a.dx, 0, a.dx_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  typedef __attribute__((address_space(3))) void* lds_ptr;
   const int tap_stride = a.CinP * a.CoutP * 2;
+  [[maybe_unused]] const BufSrd imr = make_srd(a.img, a.img_bytes);
+  [[maybe_unused]] f32x4 acc_w[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  if constexpr (FB) {
+    // the image layer's weights as MFMA rows (co) x 32 columns (3 tap + ci; 27.. = 0) in the 16-bit rounding its forward used,
+    // and its bias: visible to every wave after the first step's barrier
+    unsigned short* sW0 = reinterpret_cast<unsigned short*>(smem + FB_W0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid * 4 + e, co = idx >> 5, col = idx & 31;
+      const int tap = col / 3, ci = col - 3 * tap;
+      sW0[idx] = (col < 27 && ci < a.Cin0) ? f2h<DT>(a.w0[(co * a.Cin0 + ci) * 9 + tap]) : (unsigned short)0;
+    }
+    if (tid < 64) reinterpret_cast<float*>(smem + FB_B0)[tid] = a.b0 ? a.b0[tid] : 0.f;
+  }
+  // FB: one 64-pixel piece `pc` of image halo row `row` of the tile whose dx origin is (n, Y0, X0) -> 1 KB at dst
+  [[maybe_unused]] auto halo_piece = [&](int n, int Y0, int X0, int row, int pc, unsigned char* dst) {
+    int lo = lane;
+    asm volatile("" : "+v"(lo));       // (opaque: hipcc otherwise keeps the 13 column indices and range tests of a tile's pieces in
+    const int sl = pc * 64 + lo;       //  registers across the whole tile loop and spills to scratch -- a VMEM operation -- to do so)
+    // slot sl of a halo row holds halo column 2 sl (sl < 257) or 2 (sl - 257) + 1: even columns first, then the odd ones -- the
+    // pixels of one output-parity class are every other column, and the im2col builder's lanes then read slots 16 bytes
+    // apart instead of 32 (8-way -> 2-way bank conflicts on its 2-byte reads)
+    const int hc = sl < 257 ? 2 * sl : 2 * (sl - 257) + 1;
+    const int iy = Y0 - 1 + row, ix = X0 - 1 + hc;
+    const bool ok = sl < 514 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    lds_dma16(imr, dst, ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * 16) : OOB);
+  };
 
   // the block's tile t = (pixel tile, 64-channel block of dx): loader addresses
   auto setup = [&](int t) {
@@ -87,15 +153,13 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool inb = a_gy[i] + sy < a.OH && a_gx[i] + sx < a.OW;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(dyr, (lds_ptr)(st + (wave * 8 + 64 * i) * 128), 16,
-                                               inb ? (unsigned)(a_base[i] + toff) : OOB, 0, 0, 0);
+      lds_dma16(dyr, st + (wave * 8 + 64 * i) * 128, inb ? (unsigned)(a_base[i] + toff) : OOB);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int tap = s == 0 ? s2_tap(c, 0) : (s == 1 ? s2_tap(c, 1) : (s == 2 ? s2_tap(c, 2) : s2_tap(c, 3)));
       if (tap >= 0)                                                     // (uniform)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(st + S2_A + c * S2_BSLOT + wave * 8 * 128), 16,
-                                                 (unsigned)(b_base + tap * tap_stride + kb * 128), 0, 0, 0);
+        lds_dma16(wr, st + S2_A + c * S2_BSLOT + wave * 8 * 128, (unsigned)(b_base + tap * tap_stride + kb * 128));
     }
   };
 
@@ -110,6 +174,10 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
   int t = xcd_remap(blockIdx.x, gridDim.x);
   int q = 0;               // global step counter: stage = q & 1
   bool first_tile = true;
+#ifdef DSR_S2_STAMPS
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
   if (t < ntiles) {
     setup(t);
     dma_issue(3, 0, 0);
@@ -129,12 +197,19 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
 #pragma unroll
     for (int s = 3; s >= 0; --s) {
       for (int kb = 0; kb < a.kblocks; ++kb, ++q) {
-        if (s == 3 && kb == 0 && !first_tile)
+        S2_STAMP(tw0);
+        if (FB && s == 1)
+          asm volatile("s_waitcnt vmcnt(3)" ::: "memory");    // this step's DMA has landed; the 3 (4) halo pieces behind it fly on
+        else if (!FB && s == 3 && kb == 0 && !first_tile)
           asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the previous tile's stores stay in flight
         else
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        S2_STAMP(tw1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        S2_STAMP(tw2);
+        S2_ADD((s == 3 && kb == 0) ? 0 : 1, tw1 - tw0);
+        S2_ADD((s == 3 && kb == 0) ? 2 : 3, tw2 - tw1);
         const int cur = q & 1;
         const unsigned char* pa = smem + cur * S2_STAGE + (wm * 128 + r16) * 128;
         const unsigned char* pb = smem + cur * S2_STAGE + S2_A + (wn * 16 + r16) * 128;
@@ -146,6 +221,19 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
           } else if (tn < ntiles) {                           // (uniform) next tile's first step
             setup(tn);
             dma_issue(3, 0, cur ^ 1);
+          }
+          if constexpr (FB) {
+            if (s == 2) {
+              // image halo rows 0..2 of THIS tile, behind this step's DMA: the next step waits with vmcnt(3), the one after
+              // it with vmcnt(0) -- two steps of flight.  27 pieces over 8 waves (wave-uniform)
+              const int n = fd_div(a.fd_ghw, m0), rem = m0 - n * (a.OH * a.OW);
+              const int gy = fd_div(a.fd_gw, rem), gx0 = rem - gy * a.OW;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int jj = wave + 8 * r;
+                if (jj < 27) halo_piece(n, 2 * gy, 2 * gx0, jj / 9, jj % 9, smem + FB_HALO + (jj / 9) * FB_ROWP + (jj % 9) * 1024);
+              }
+            }
           }
         };
         // 16 (k-half, pixel fragment) units as a software pipeline: the A fragment of unit u + 2 is requested before the
@@ -183,12 +271,152 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
       }
     }
     first_tile = false;
+    S2_STAMP(te0);
     // ---- epilogue: class by class, 256 pixels x 64 channels through LDS (the stage the last step read: the other one is
     // receiving the next tile), then full 128-byte lines to dx.  Raw barriers: a __syncthreads() would drain the DMA.
     unsigned char* sC = smem + ((q - 1) & 1) * S2_STAGE;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                             // every wave is done reading that stage
     asm volatile("" ::: "memory");
+    if constexpr (FB) {
+      unsigned char* sBim = sC + FB_IM;
+      {   // 4th image halo row, into the stage that has just been freed: needed from class 2 on
+        const int n = fd_div(a.fd_ghw, m0), rem = m0 - n * (a.OH * a.OW);
+        const int gy = fd_div(a.fd_gw, rem), gx0 = rem - gy * a.OW;
+        halo_piece(n, 2 * gy, 2 * gx0, 3, wave, sC + FB_ROW3 + wave * 1024);
+        if (wave == 0) halo_piece(n, 2 * gy, 2 * gx0, 3, 8, sC + FB_ROW3 + 8 * 1024);
+      }
+      int tio = tid;
+      asm volatile("" : "+v"(tio));                           // (opaque, as above: everything below is re-derived per tile)
+      const int r16 = tio & 15, g = (tio >> 4) & 3;           // (shadow the kernel-wide ones)
+      const U4 fw0 = *reinterpret_cast<const U4*>(smem + FB_W0 + (wn * 16 + r16) * 64 + g * 16);
+      const f32x4 bias0 = *reinterpret_cast<const f32x4*>(smem + FB_B0 + (wn * 16 + 4 * g) * 4);
+      const int q4 = r16 >> 2, cc = 4 * (r16 & 3);
+      const int bp = tio & 255;                               // im2col builder: this thread's pixel; its two 8-column chunks are wm, wm + 2
+      const unsigned char* hA = smem + FB_HALO + bp * 16;     // halo rows 0..2: + row * FB_ROWP + slot(pw + kw) * 16 + ci * 2
+      const unsigned char* hB = sC + FB_ROW3 + bp * 16;       // halo row 3
+      constexpr unsigned short ONE = DT == DSR_DTYPE_BF16 ? 0x3F80 : 0x3C00;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ph = c >> 1, pw = c & 1;
+        // ---- im2col image of the class's 256 pixels (pixel p of the tile <-> dx pixel (2 gy + ph, 2 (gx0 + p) + pw)): every
+        // offset is an immediate inside each of the two wave-uniform branches
+        auto build = [&](auto chunk0) {
+          constexpr int CH0 = decltype(chunk0)::value;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int ch = CH0 + 2 * u;
+            unsigned short e[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int col = 8 * ch + i;
+              const int tap = col / 3, ci = col - 3 * tap, kh = tap / 3, kw = tap - 3 * kh;
+              const int row = ph + kh;
+              const int hs = ((pw + kw) & 1) * 257 + ((pw + kw) >> 1);      // slot of halo column 2 p + pw + kw, less p
+              if (col < 27)
+                e[i] = *reinterpret_cast<const unsigned short*>((row < 3 ? hA + row * FB_ROWP : hB) + hs * 16 + ci * 2);
+              else
+                e[i] = col == 27 ? ONE : (unsigned short)0;
+            }
+            U4 v;
+            v.x = e[0] | ((unsigned)e[1] << 16);
+            v.y = e[2] | ((unsigned)e[3] << 16);
+            v.z = e[4] | ((unsigned)e[5] << 16);
+            v.w = e[6] | ((unsigned)e[7] << 16);
+            *reinterpret_cast<U4*>(sBim + bp * 64 + ((ch ^ ((bp >> 1) & 3)) << 4)) = v;
+          }
+        };
+        S2_STAMP(tf0);
+        if (wm == 0)
+          build(std::integral_constant<int, 0>{});
+        else
+          build(std::integral_constant<int, 1>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        S2_STAMP(tf1);
+        __builtin_amdgcn_s_barrier();                         // the im2col image is complete
+        asm volatile("" ::: "memory");
+        S2_STAMP(tf2);
+        // ---- pre-activation of the image layer for this wave's 8 x (16 pixels x 16 channels), mask, C tile
+        // (one instantiation per activation, chosen by a wave-uniform branch: 3 vector instructions per element + the packed
+        //  conversion; with the activation as a run-time value this loop was the longest phase of the epilogue)
+        auto mask_store = [&](auto actc) {
+          constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+          for (int i0 = 0; i0 < 8; i0 += 4) {                 // four fragments at a time: reads, then MFMAs, then the mask
+            U4 fa[4];
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int row = wm * 128 + 16 * (i0 + k) + r16;
+              fa[k] = *reinterpret_cast<const U4*>(sBim + row * 64 + ((g ^ ((row >> 1) & 3)) << 4));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = mfma16<DT>(fw0, fa[k], bias0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int i = i0 + k;
+              const int row = wm * 128 + 16 * i + r16;
+              float o[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {   // g = d * act'(v): fp32 product, ONE rounding (the two-kernel path rounds d first)
+                const float d = acc[i][c][j];
+                if constexpr (ACT == DSR_ACT_LEAKY)
+                  o[j] = v[k][j] >= 0.f ? d : d * a.slope0;
+                else if constexpr (ACT == DSR_ACT_RELU)
+                  o[j] = v[k][j] > 0.f ? d : 0.f;
+                else
+                  o[j] = d;
+              }
+              uint2 h;
+              h.x = (unsigned)f2h<DT>(o[0]) | ((unsigned)f2h<DT>(o[1]) << 16);
+              h.y = (unsigned)f2h<DT>(o[2]) | ((unsigned)f2h<DT>(o[3]) << 16);
+              *reinterpret_cast<uint2*>(sC + row * S2_CSTRIDE + (wn * 16 + 4 * g) * 2) = h;
+            }
+          }
+        };
+        if (a.act0 == DSR_ACT_LEAKY)
+          mask_store(std::integral_constant<int, DSR_ACT_LEAKY>{});
+        else if (a.act0 == DSR_ACT_RELU)
+          mask_store(std::integral_constant<int, DSR_ACT_RELU>{});
+        else
+          mask_store(std::integral_constant<int, DSR_ACT_NONE>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        S2_STAMP(tf3);
+        __builtin_amdgcn_s_barrier();                         // the masked C tile is complete
+        asm volatile("" ::: "memory");
+        S2_STAMP(tf4);
+        // ---- D[co = 16 wn + ..][col] += sum over this wave's 128 pixels (4 K-steps of 32)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int p1 = wm * 128 + 32 * ks + 4 * g + q4, p2 = p1 + 16;
+          U4 fa, fb[2];
+          {
+            const s16x4 lo = s2_tr_read(sC + p1 * S2_CSTRIDE + (16 * wn + cc) * 2);
+            const s16x4 hi = s2_tr_read(sC + p2 * S2_CSTRIDE + (16 * wn + cc) * 2);
+            fa = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          }
+#pragma unroll
+          for (int nf = 0; nf < 2; ++nf) {
+            const int col = 16 * nf + cc;
+            const s16x4 lo = s2_tr_read(sBim + p1 * 64 + (((col >> 3) ^ ((p1 >> 1) & 3)) << 4) + (col & 7) * 2);
+            const s16x4 hi = s2_tr_read(sBim + p2 * 64 + (((col >> 3) ^ ((p2 >> 1) & 3)) << 4) + (col & 7) * 2);
+            fb[nf] = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          }
+          acc_w[0] = mfma16<DT>(fa, fb[0], acc_w[0]);
+          acc_w[1] = mfma16<DT>(fa, fb[1], acc_w[1]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        S2_STAMP(tf5);
+        if (c == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of halo row 3 (and the next tile's first DMA) have landed
+        __builtin_amdgcn_s_barrier();                         // C tile and im2col image have been read: the next class may overwrite them
+        asm volatile("" ::: "memory");
+        S2_STAMP(tf6);
+        S2_ADD(7, tf1 - tf0);
+        S2_ADD(8, tf3 - tf2);
+        S2_ADD(9, tf5 - tf4);
+        S2_ADD(10, (tf2 - tf1) + (tf4 - tf3) + (tf6 - tf5));
+      }
+    } else {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int ph = c >> 1, pw = c & 1;
@@ -221,7 +449,25 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
       __builtin_amdgcn_s_barrier();                           // the C tile has been read: the next class may overwrite it
       asm volatile("" ::: "memory");
     }
+    }
+    S2_STAMP(te1);
+    S2_ADD(4, te1 - te0);
+    S2_ADD(5, 1);
   }
+  if constexpr (FB) {
+    // partial[2 block + wm][co][32]: lane (g, r16) holds D[co = 16 wn + 4 g + j][col = 16 nf + r16]
+    float* P = a.fb_partial + ((size_t)blockIdx.x * 2 + wm) * 64 * 32;
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) P[(16 * wn + 4 * g + j) * 32 + 16 * nf + r16] = acc_w[nf][j];
+  }
+#ifdef DSR_S2_STAMPS
+  if (tid == 0) {
+    st_acc[6] = __builtin_amdgcn_s_memtime() - st_begin;
+    for (int i = 0; i < 12; ++i) s2_stamps[blockIdx.x][i] = st_acc[i];
+  }
+#endif
 }
 
 bool dsr_dgrad_s2_supported(int KH, int KW, int stride, int pad, int pad_mode, int H, int W, int CinP, int CoutP, int N) {
@@ -249,11 +495,26 @@ void dsr_launch_dgrad_s2(DgradS2Args& a, int N, int dtype, hipStream_t st) {
   a.dx_bytes = (unsigned)((size_t)N * a.H * a.W * a.CinP * 2);
   const int ntiles = a.tiles_m * a.ci_blocks;
   const int blocks = ntiles < 256 ? ntiles : 256;          // persistent: one 8-wave block per CU (128 KB of LDS each)
-  static LdsOptIn optin[2];   // more than 64 KB of dynamic LDS needs the opt-in, once per kernel and device (not a stream operation)
-  optin[0].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_BF16>, S2_LDS);
-  optin[1].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_F16>, S2_LDS);
+  static LdsOptIn optin[4];   // more than 64 KB of dynamic LDS needs the opt-in, once per kernel and device (not a stream operation)
+  if (a.img) {                // the first-layer backward in the epilogue (dsr_conv_dgrad_first_bwd checked the shape)
+    optin[2].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_BF16, true>, FB_LDS);
+    optin[3].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_F16, true>, FB_LDS);
+    if (dtype == DSR_DTYPE_BF16)
+      hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_BF16, true>), dim3(blocks), dim3(512), FB_LDS, st, a);
+    else
+      hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_F16, true>), dim3(blocks), dim3(512), FB_LDS, st, a);
+    return;
+  }
+  optin[0].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_BF16, false>, S2_LDS);
+  optin[1].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_F16, false>, S2_LDS);
   if (dtype == DSR_DTYPE_BF16)
-    hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_BF16>), dim3(blocks), dim3(512), S2_LDS, st, a);
+    hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_BF16, false>), dim3(blocks), dim3(512), S2_LDS, st, a);
   else
-    hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_F16>), dim3(blocks), dim3(512), S2_LDS, st, a);
+    hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_F16, false>), dim3(blocks), dim3(512), S2_LDS, st, a);
+}
+
+// blocks of a launch (the fused form writes two partial rows per block)
+int dsr_dgrad_s2_blocks(int N, int H, int W, int CinP) {
+  const long long ntiles = (((long long)N * (H / 2) * (W / 2) + S2_BM - 1) / S2_BM) * (CinP / 64);
+  return (int)(ntiles < 256 ? ntiles : 256);
 }

@@ -16,6 +16,7 @@
 // (16 pixels x 16 channels) against the layer's own 27 x 64 weights recomputes v = conv(x) + b in fp32, and g = dout * act'(v).
 // The 1.07 GB activation of D's first layer (config 3) is then read by this pass no more: 2.15 -> 1.1 GB.
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../include/dsr_hip.h"
 #include "dsr_common.h"
@@ -335,4 +336,55 @@ extern "C" int dsr_conv_first_bwd_recompute(const dsr_conv_desc* d, const void* 
                                             size_t ws_bytes, dsr_stream_t s) {
   if (!w) return dsr_fail(DSR_E_ARG, "conv_first_bwd_recompute: null weight pointer");
   return first_bwd_impl(d, x, dout, nullptr, w, bias, act, slope, dw, db, workspace, ws_bytes, s);
+}
+
+// ---- the stride-2 layer's input gradient and this layer's backward as ONE launch (conv_dgrad_s2_kernel<FB>, conv_dgrad_s2.hip):
+// d0 = the image layer (discriminator.py:25), d1 = the 3x3 stride-2 64 -> 64 layer on top of it (:29).  dy = the gradient of d1's
+// conv output, w1_dgrad = d1's packed input-gradient weights; the gradient of the 64-channel activation in between is formed per
+// tile in LDS, masked by this layer's activation derivative (pre-activation recomputed from `img`, `w0`, `b0`) and contracted
+// with the im2col image there -- it never exists in HBM.  Only dw0 / db0 come out: for a step that needs no image gradient.
+static bool dgrad_first_bwd_ok(const dsr_conv_desc* d0, const dsr_conv_desc* d1, int act0) {
+  const char* e = getenv("DSR_DGRAD_FIRST_BWD");     // tuning switch, read per call: 0 = never
+  if (e && e[0] == '0') return false;
+  if (!d0 || !d1 || !dsr_conv_first_bwd_supported(d0, act0)) return false;
+  if (d1->dtype != d0->dtype || d1->N != d0->N || d1->H != d0->H || d1->W != d0->W || d1->Cin != 64 || d1->Cout != 64) return false;
+  if (d1->KH != 3 || d1->KW != 3 || d1->stride != 2 || d1->pad != 1 || d1->pad_mode != DSR_PAD_ZERO) return false;
+  if ((d1->H & 1) || (d1->W & 1) || (d1->W / 2) % 256 != 0) return false;      // a tile = 256 consecutive dY pixels of ONE row
+  return (size_t)d1->N * d1->H * d1->W * 128 < (1ull << 31);
+}
+extern "C" int dsr_conv_dgrad_first_bwd_supported(const dsr_conv_desc* d0, const dsr_conv_desc* d1, int act0) {
+  return dgrad_first_bwd_ok(d0, d1, act0) ? 1 : 0;
+}
+extern "C" size_t dsr_conv_dgrad_first_bwd_workspace(const dsr_conv_desc* d1) {
+  if (!d1) return 0;
+  return (size_t)2 * dsr_dgrad_s2_blocks(d1->N, d1->H, d1->W, 64) * 64 * 32 * sizeof(float);
+}
+extern "C" int dsr_conv_dgrad_first_bwd(const dsr_conv_desc* d0, const dsr_conv_desc* d1, const void* dy, const void* w1_dgrad,
+                                        const void* img, const float* w0, const float* b0, int act0, float slope0, float* dw0,
+                                        float* db0, void* workspace, size_t ws_bytes, dsr_stream_t s) {
+  if (!dgrad_first_bwd_ok(d0, d1, act0)) return dsr_fail(DSR_E_UNSUPPORTED, "conv_dgrad_first_bwd: unsupported layer pair");
+  if (!dy || !w1_dgrad || !img || !w0 || !dw0) return dsr_fail(DSR_E_ARG, "conv_dgrad_first_bwd: null pointer");
+  const size_t need = dsr_conv_dgrad_first_bwd_workspace(d1);
+  if (!workspace || ws_bytes < need) return dsr_fail(DSR_E_WORKSPACE, "conv_dgrad_first_bwd: workspace %zu < %zu", ws_bytes, need);
+  DgradS2Args q;
+  memset(&q, 0, sizeof(q));
+  q.dy = dy;
+  q.w = w1_dgrad;
+  q.dx = nullptr;                                    // (never written)
+  q.H = d1->H;
+  q.W = d1->W;
+  q.CinP = 64;
+  q.CoutP = 64;
+  q.img = img;
+  q.w0 = w0;
+  q.b0 = b0;
+  q.fb_partial = (float*)workspace;
+  q.img_bytes = (unsigned)((size_t)d0->N * d0->H * d0->W * 16);
+  q.Cin0 = d0->Cin;
+  q.act0 = act0;
+  q.slope0 = slope0;
+  dsr_launch_dgrad_s2(q, d1->N, d1->dtype, s);
+  const int rows = 2 * dsr_dgrad_s2_blocks(d1->N, d1->H, d1->W, 64);
+  hipLaunchKernelGGL(first_bwd_finalize_kernel, dim3(64), dim3(256), 0, s, (const float*)workspace, rows, d0->Cin, dw0, db0);
+  return dsr_launch_status("dsr_conv_dgrad_first_bwd");
 }

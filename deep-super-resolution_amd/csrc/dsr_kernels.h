@@ -229,7 +229,16 @@ struct DgradS2Args {
   int OH, OW, M, ci_blocks, kblocks, tiles_m;      // filled by the launcher
   unsigned dy_bytes, w_bytes, dx_bytes;
   FastDiv fd_ghw, fd_gw;
+  // the image layer's backward in the epilogue (dsr_conv_dgrad_first_bwd; img == nullptr: plain input gradient)
+  const void* img;        // [N][H][W][8] the image layer's input
+  const float* w0;        // its weights [64][Cin0][3][3], fp32
+  const float* b0;        // its bias [64] or nullptr
+  float* fb_partial;      // [2 blocks][64][32]
+  unsigned img_bytes;
+  int Cin0, act0;
+  float slope0;
 };
+int dsr_dgrad_s2_blocks(int N, int H, int W, int CinP);
 bool dsr_dgrad_s2_supported(int KH, int KW, int stride, int pad, int pad_mode, int H, int W, int CinP, int CoutP, int N);
 void dsr_launch_dgrad_s2(DgradS2Args& a, int N, int dtype, hipStream_t st);
 

@@ -482,6 +482,12 @@ class ConvAct(torch.autograd.Function):
         prelu = prelu if prelu.numel() else None
         lib = _lib.lib()
         desc = ctx.desc
+        link = ctx.cfg.get("first2_link")
+        if link is not None and "grads" in link:
+            # the layer on top of this one (ConvBNAct with cfg["first2"]) ran this layer's whole backward inside its own input-
+            # gradient kernel (dsr_conv_dgrad_first_bwd) and left the results here; `dout` is a placeholder without storage
+            dw, db = link.pop("grads")
+            return None, dw, db, None, None
         dout = dout.contiguous()
         cout = desc.Cout
         n = x.shape[0]
@@ -543,6 +549,37 @@ class ConvAct(torch.autograd.Function):
         return dx, dw, db, dprelu, None
 
 
+FIRST2_BACKWARD = os.environ.get("DSR_FIRST2_BACKWARD", "1") != "0"   # 0: the first two layers' backward as separate launches
+
+
+def _first2_backward(ctx, desc, x, dy, wd):
+    """discriminator.py:25-29 in a step that needs no image gradient (the discriminator's own update): this layer's input
+    gradient and the image layer's whole backward (mask, bias and weight gradient) as one launch, dsr_conv_dgrad_first_bwd --
+    the gradient of the 64-channel activation between the two (1.07 GB at 512x512, batch 32) is never written.  Returns the
+    placeholder to hand to autograd as that gradient (the image layer's gradients are left in the link its ConvAct node
+    reads), or None when the pair does not qualify: then the caller takes the separate launches."""
+    first2 = ctx.cfg.get("first2")
+    if not FIRST2_BACKWARD or first2 is None or len(first2) < 5 or first2[4] is None or not ctx.needs_input_grad[0]:
+        return None
+    img, w0, b0, slope0, link = first2
+    if (img.requires_grad or not w0.requires_grad or w0.dtype != torch.float32 or not w0.is_contiguous()
+            or _version(w0) != getattr(ctx, "first2_w0_version", None) or (b0 is not None and not b0.requires_grad)):
+        return None
+    lib = _lib.lib()
+    d0 = make_desc(img, w0.shape[0], 3, 3, 1, 1, PAD_ZERO, w0.shape[1])
+    if not lib.dsr_conv_dgrad_first_bwd_supported(C.byref(d0), C.byref(desc), ACT_LEAKY):
+        return None
+    dw0 = torch.empty(tuple(w0.shape), dtype=torch.float32, device=x.device)
+    db0 = torch.empty(w0.shape[0], dtype=torch.float32, device=x.device) if b0 is not None else None
+    wsz = lib.dsr_conv_dgrad_first_bwd_workspace(C.byref(desc))
+    ws = torch.empty(wsz, dtype=torch.uint8, device=x.device)
+    check(_timed("dgrad", desc, lambda: lib.dsr_conv_dgrad_first_bwd(
+        C.byref(d0), C.byref(desc), _ptr(dy), _ptr(wd), _ptr(img), _ptr(w0.detach()), _ptr(b0.detach() if b0 is not None else None),
+        ACT_LEAKY, float(slope0), _ptr(dw0), _ptr(db0), _ptr(ws), wsz, _stream()), name="conv_dgrad_s2_kernel<first_bwd>"))
+    link["grads"] = (dw0, db0)
+    return torch.empty(1, dtype=x.dtype, device=x.device).expand(x.shape)
+
+
 # ----------------------------------------------------------------------------- conv + BatchNorm + activation (+ residual)
 class ConvBNAct(torch.autograd.Function):
     """out = act(BN(conv(x, W) + b)) [+ residual]   (train or eval mode BatchNorm2d).
@@ -584,7 +621,8 @@ class ConvBNAct(torch.autograd.Function):
             # x is the (not yet computed) output of the image layer in front of this one: both convolutions run in ONE kernel
             # that recomputes that activation per tile in LDS (dsr_conv_first2_fwd) and writes it to x only when a backward
             # pass will read it (this layer's weight gradient); the forward itself never reads it back from HBM
-            img, w0, b0, slope0 = first2
+            img, w0, b0, slope0 = first2[:4]
+            ctx.first2_w0_version = _version(w0)
             d0 = make_desc(img, w0.shape[0], 3, 3, 1, 1, PAD_ZERO, w0.shape[1])
             wf0, _ = packed_weights(w0, d0, x.dtype)
             rows = lib.dsr_conv_first2_stats_rows(C.byref(d0))
@@ -688,8 +726,15 @@ class ConvBNAct(torch.autograd.Function):
         check(lib.dsr_pw_bn_act_bwd_apply(_dt(x), _ptr(dout), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
                                           _ptr(c1), _ptr(c2), _ptr(dy), p, cp, ctx.act, slope, _ptr(prelu),
                                           int(ctx.train), _stream()))
-        dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape,
-                                 getattr(ctx, "weight_ref", None), dcarry)
+        fused = _first2_backward(ctx, desc, x, dy, wd) if dcarry is None else None
+        if fused is not None:
+            # the input gradient (of the image layer's activation) was consumed where it was formed: autograd gets a
+            # placeholder of the right shape without storage, and the image layer's ConvAct node finds its gradients in the link
+            dx = fused
+            _, dw = _conv_backward(desc, x, dy, wd, False, ctx.needs_input_grad[1], ctx.wshape, getattr(ctx, "weight_ref", None))
+        else:
+            dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape,
+                                     getattr(ctx, "weight_ref", None), dcarry)
         db = None
         if ctx.has_bias and not ctx.train:
             # a bias in front of a train-mode BatchNorm has an analytically zero gradient (the reference holds ~1e-9

@@ -70,10 +70,13 @@ class Discriminator(nn.Module):
         fused = blk0.training and F.first2_supported(xi, self.conv.weight, blk0.conv1.weight, blk0.stride)
         # fused: the first layer is computed INSIDE the second layer's forward kernel (its 64-channel activation, 1.07 GB at
         # 512x512 x 32, is recomputed per tile and written only for a backward pass); ConvAct then only allocates and records
+        # (`link`: where the fused backward of the two layers, dsr_conv_dgrad_first_bwd, leaves the first layer's gradients for
+        #  its autograd node -- a step that needs no image gradient never writes the gradient of the activation between them)
+        link = {} if fused else None
         z = F.ConvAct.apply(xi, self.conv.weight, self.conv.bias, None,
-                            dict(stride=1, pad=1, act=F.ACT_LEAKY, slope=0.2, defer=fused))  # :60-61
+                            dict(stride=1, pad=1, act=F.ACT_LEAKY, slope=0.2, defer=fused, first2_link=link))  # :60-61
         for i, blk in enumerate(self.convblocks):                                             # :63
-            z = blk._block(z, (xi, self.conv.weight, self.conv.bias, 0.2) if (fused and i == 0) else None)
+            z = blk._block(z, (xi, self.conv.weight, self.conv.bias, 0.2, link) if (fused and i == 0) else None)
         return z
 
     def head(self, z):

@@ -107,6 +107,19 @@ int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const void* dout, 
 int dsr_conv_first_bwd_recompute(const dsr_conv_desc* d, const void* x, const void* dout, const float* w, const float* bias,
                                  int act, float slope, float* dw, float* db, void* workspace, size_t ws_bytes, dsr_stream_t s);
 
+/* The backward counterpart of dsr_conv_first2_fwd for a step that needs no image gradient (the discriminator's own update,
+ * train_GAN.py:47-56): the input gradient of the stride-2 layer d1 (discriminator.py:29) and the whole backward of the image
+ * layer d0 under it (:25-27: activation mask, bias gradient, weight gradient) in ONE launch.  The gradient of the 64-channel
+ * activation between them (1.07 GB at 512x512, batch 32) is formed per tile in LDS and never written.  dy: gradient of d1's
+ * conv output [N][H/2][W/2][64]; w1_dgrad: d1's packed input-gradient weights (dsr_conv_pack_weight); img: NHWC 16-bit image
+ * with 8 channels; w0 (OIHW fp32) / b0 (nullable): d0's parameters as the forward used them; dw0 (OIHW fp32), db0 (nullable).
+ * _supported(): 64 -> 64 channels, even H and W with (W/2) % 256 == 0, d0 as dsr_conv_first_bwd_supported. */
+int dsr_conv_dgrad_first_bwd_supported(const dsr_conv_desc* d0, const dsr_conv_desc* d1, int act0);
+size_t dsr_conv_dgrad_first_bwd_workspace(const dsr_conv_desc* d1);
+int dsr_conv_dgrad_first_bwd(const dsr_conv_desc* d0, const dsr_conv_desc* d1, const void* dy, const void* w1_dgrad,
+                             const void* img, const float* w0, const float* b0, int act0, float slope0, float* dw0, float* db0,
+                             void* workspace, size_t ws_bytes, dsr_stream_t s);
+
 /* The discriminator's first two convolutions (discriminator.py:25 Conv2d(3,64,3,1,1) + LeakyReLU; :29 Conv2d(64,64,3,2,1) in
  * front of its BatchNorm) as ONE forward launch: the first layer's 64-channel activation (1.07 GB at 512x512, batch 32) is
  * recomputed per tile in LDS and goes to HBM only if `a0` is given (training: the second layer's weight gradient reads it).

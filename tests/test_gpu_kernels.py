@@ -482,6 +482,76 @@ def test_first_layer_fused_backward(dev, n, h, w, actn):
     assert rel_err(dw_f, dw_u) < 5e-3 and rel_err(db_f, db_u) < 5e-3
 
 
+@pytest.mark.parametrize("n,h,w,cin,actn", [(2, 6, 512, 3, "leaky"), (1, 4, 1024, 3, "relu"), (3, 2, 512, 1, "leaky"), (130, 4, 512, 3, "leaky")])
+def test_first_two_layers_fused_backward(dev, n, h, w, cin, actn):
+    """dsr_conv_dgrad_first_bwd -- the input gradient of discriminator.py:29 (Conv2d(64,64,3,2,1)) and the whole backward of
+    :25-27 (Conv2d(3,64,3,1,1) + LeakyReLU: mask, bias gradient, weight gradient) as ONE launch that never writes the gradient
+    of the 64-channel activation in between -- against (a) the two launches it replaces (dsr_conv_dgrad, then
+    dsr_conv_first_bwd_recompute on the stored gradient, which is rounded to bf16 before the mask where the one launch rounds
+    the masked fp32 value once) and (b) float64 PyTorch on the same bf16 operands with g rounded where each path rounds it.  Image rows of one and two tiles,
+    the top / bottom / left / right image borders in every tile, a one-channel image, more tiles than persistent blocks."""
+    import ctypes as C
+    L = P("_lib")
+    F = P("functional")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    act = dict(leaky=F.ACT_LEAKY, relu=F.ACT_RELU)[actn]
+    g = torch.Generator(device="cpu").manual_seed(h * w + n)
+    x = bfr(torch.rand(n, cin, h, w, generator=g) * 2 - 1)
+    w0 = (torch.rand(64, cin, 3, 3, generator=g) - 0.5) * 0.6
+    b0 = (torch.rand(64, generator=g) - 0.5) * 0.2
+    w1 = bfr((torch.rand(64, 64, 3, 3, generator=g) - 0.5) * 0.1)
+    oh, ow = h // 2, w // 2
+    dy = bfr(torch.rand(n, 64, oh, ow, generator=g) - 0.5)
+    d0 = L.ConvDesc(L.BF16, n, h, w, cin, 64, 3, 3, 1, 1, 0)
+    d1 = L.ConvDesc(L.BF16, n, h, w, 64, 64, 3, 3, 2, 1, 0)
+    assert lib.dsr_conv_dgrad_first_bwd_supported(C.byref(d0), C.byref(d1), act) == 1
+    wd1 = torch.empty(lib.dsr_conv_packed_elems(C.byref(d1), 1), dtype=torch.bfloat16, device=dev)
+    wf1 = torch.empty(lib.dsr_conv_packed_elems(C.byref(d1), 0), dtype=torch.bfloat16, device=dev)
+    L.check(lib.dsr_conv_pack_weight(C.byref(d1), w1.to(dev).data_ptr(), wf1.data_ptr(), wd1.data_ptr(), st))
+    xg = to_nhwc(x).to(dev)
+    dyg = to_nhwc(dy, 64).to(dev)
+    w0g, b0g = w0.to(dev), b0.to(dev)
+    # ---- one launch
+    dw_f = torch.full((64, cin, 3, 3), float("nan"), dtype=torch.float32, device=dev)
+    db_f = torch.full((64,), float("nan"), dtype=torch.float32, device=dev)
+    wsz = lib.dsr_conv_dgrad_first_bwd_workspace(C.byref(d1))
+    ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+    L.check(lib.dsr_conv_dgrad_first_bwd(C.byref(d0), C.byref(d1), dyg.data_ptr(), wd1.data_ptr(), xg.data_ptr(), w0g.data_ptr(),
+                                         b0g.data_ptr(), act, 0.2, dw_f.data_ptr(), db_f.data_ptr(), ws.data_ptr(), wsz, st))
+    # ---- two launches
+    da0 = torch.full((n, h, w, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    wsz2 = lib.dsr_conv_dgrad_workspace(C.byref(d1))
+    ws2 = torch.empty(max(wsz2, 16), dtype=torch.uint8, device=dev)
+    L.check(lib.dsr_conv_dgrad(C.byref(d1), dyg.data_ptr(), wd1.data_ptr(), da0.data_ptr(), ws2.data_ptr(), wsz2, st))
+    dw_t = torch.empty((64, cin, 3, 3), dtype=torch.float32, device=dev)
+    db_t = torch.empty((64,), dtype=torch.float32, device=dev)
+    wsz3 = lib.dsr_conv_first_bwd_workspace(C.byref(d0))
+    ws3 = torch.empty(wsz3, dtype=torch.uint8, device=dev)
+    L.check(lib.dsr_conv_first_bwd_recompute(C.byref(d0), xg.data_ptr(), da0.data_ptr(), w0g.data_ptr(), b0g.data_ptr(), act, 0.2,
+                                             dw_t.data_ptr(), db_t.data_ptr(), ws3.data_ptr(), wsz3, st))
+    torch.cuda.synchronize()
+    dw_f, db_f, dw_t, db_t = dw_f.cpu().double(), db_f.cpu().double(), dw_t.cpu().double(), db_t.cpu().double()
+    assert torch.isfinite(dw_f).all() and torch.isfinite(db_f).all()
+    sw, sb = float(dw_t.abs().max()), float(db_t.abs().max())
+    # g rounded once (one launch) against twice (two launches), fp32 partial sums in another order, and a sign that can flip
+    # where the recomputed pre-activation is within fp32 noise of zero
+    assert float((dw_f - dw_t).abs().max()) < 5e-3 * sw and float((db_f - db_t).abs().max()) < 5e-3 * sb
+    # ---- float64 reference
+    xd, w0d = x.double(), bfr(w0).double()
+    z0 = TF.conv2d(xd, w0d, b0.double(), padding=1)
+    da_ref = TF.conv_transpose2d(dy.double(), w1.double(), stride=2, padding=1, output_padding=1)
+    mask = torch.where(z0 >= 0, torch.ones_like(z0), torch.full_like(z0, 0.2 if actn == "leaky" else 0.0))
+    if actn == "relu":
+        mask = (z0 > 0).double()
+    for got_w, got_b, twice in ((dw_f, db_f, False), (dw_t, db_t, True)):
+        d_in = bfr(da_ref.float()).double() if twice else da_ref          # two launches: the gradient is stored in bf16 first
+        gref = bfr((d_in * mask).float()).double()
+        dw_r = torch.nn.grad.conv2d_weight(xd, (64, cin, 3, 3), gref, padding=1)
+        db_r = gref.sum(dim=(0, 2, 3))
+        assert rel_err(got_w, dw_r) < 1e-3 and rel_err(got_b, db_r) < 1e-3, twice
+
+
 @pytest.mark.parametrize("n,h,w,keep", [(2, 64, 64, True), (3, 37, 70, True), (1, 128, 200, False), (33, 16, 128, True)])
 def test_first_two_layers_fused_forward(dev, n, h, w, keep):
     """dsr_conv_first2_fwd -- discriminator.py:25 (Conv2d(3,64,3,1,1) + LeakyReLU(0.2)) and :29 (Conv2d(64,64,3,2,1) in front of its

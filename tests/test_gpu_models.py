@@ -325,6 +325,60 @@ def test_discriminator_fused_first_two_layers_equal_two_launches(dev, need_dx, m
         assert rel_err(ra[k], rb[k]) < 2e-3, k
 
 
+def test_discriminator_fused_backward_of_first_two_layers(dev, monkeypatch):
+    """An image that needs no gradient (the discriminator's own update, train_GAN.py:47-56): ConvBNAct.backward of the second
+    layer runs its input gradient AND the image layer's whole backward as one launch (dsr_conv_dgrad_first_bwd) and hands the
+    image layer's gradients to its autograd node through the link; DSR_FIRST2_BACKWARD off runs the separate launches.  Same
+    module, weights and batch: the output and every gradient except the image layer's are BIT-identical (nothing else
+    changed), conv.weight / conv.bias agree to the rounding of the masked gradient (once vs twice) and with the oracle.  Needs
+    an image row of 512 pixels (a tile is 256 gradient pixels of ONE row); with an image that requires grad the launch is
+    not taken and the two settings are bit-identical throughout."""
+    Dm = P("models.GAN.discriminator")
+    F = P("functional")
+    hw = (16, 512)
+    n = 2
+    sd = filler.fill_state_dict(gan.template(gan.discriminator_shapes(hw)))
+    x = filler.tensor("in:disc_fb", (n, 3, hw[0], hw[1]))
+    probe = filler.tensor("probe:disc_fb", (n, 1)).to(dev)
+    res = {}
+    names = []
+    for need_dx in (False, True):
+        for on in (True, False):
+            monkeypatch.setattr(F, "FIRST2_BACKWARD", on)
+            d = Dm.Discriminator(hw)
+            d.load_state_dict(sd)
+            d.to(dev).train()
+            xg = x.to(dev).requires_grad_(need_dx)
+            F.KERNEL_LOG = []
+            try:
+                y = d(xg)
+                (y * probe).sum().backward()
+                torch.cuda.synchronize()
+                names = [e[4] for e in F.KERNEL_LOG]
+            finally:
+                F.KERNEL_LOG = None
+            took = any("first_bwd>" in nm for nm in names)
+            assert took == (on and not need_dx), (need_dx, on, names)
+            res[(need_dx, on)] = (y.detach().clone(), {k: p.grad.clone() for k, p in d.named_parameters() if p.grad is not None})
+    for need_dx in (False, True):
+        (ya, ga), (yb, gb) = res[(need_dx, True)], res[(need_dx, False)]
+        assert torch.equal(ya, yb) and set(ga) == set(gb) and "conv.weight" in ga and "conv.bias" in ga
+        for k in ga:
+            if need_dx or k not in ("conv.weight", "conv.bias"):
+                assert torch.equal(ga[k], gb[k]), (need_dx, k)
+            else:
+                assert torch.isfinite(ga[k]).all() and rel_err(ga[k], gb[k]) < 5e-3, (k, rel_err(ga[k], gb[k]))
+    # against the oracle (fp32 CPU restatement of the reference): the first layer's gradients of the fused launch
+    osd = {k: v.clone() for k, v in sd.items()}
+    recipes.leaves(osd)
+    yr = gan.discriminator_forward(osd, x, True)
+    (yr * probe.cpu()).sum().backward()
+    ga, gb = res[(False, True)][1], res[(False, False)][1]
+    for k in ("conv.weight", "conv.bias"):      # (batch 2 through seven train-mode BatchNorms: the bf16 floor of parity_util, not 1.0)
+        cf, cu = cos(ga[k].cpu(), osd[k].grad), cos(gb[k].cpu(), osd[k].grad)
+        assert cf > 0.9 and cf > cu - 0.01, (k, cf, cu)
+
+
 @pytest.mark.parametrize("hw,n", [((32, 32), 4), ((48, 32), 3), ((64, 64), 4)])
 def test_discriminator(dev, hw, n):
     Dm = P("models.GAN.discriminator")

@@ -61,5 +61,57 @@ def main():
               f"{t_keep*1e3:7.1f} us | fused, not kept {t_drop*1e3:7.1f} us", flush=True)
 
 
+def backward():
+    """dsr_conv_dgrad_first_bwd (one launch, the 64-channel gradient between the layers never written) against the two launches
+    it replaces: dsr_conv_dgrad of the stride-2 layer, then dsr_conv_first_bwd_recompute."""
+    dev = torch.device("cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n, h, w = 32, 512, 512
+    g = torch.Generator(device="cpu").manual_seed(5)
+    xg = torch.zeros(n, h, w, 8, dtype=torch.bfloat16, device=dev)
+    xg[..., :3] = (torch.rand(n, h, w, 3, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+    w0 = ((torch.rand(64, 3, 3, 3, generator=g) - 0.5) * 0.6).to(dev)
+    b0 = ((torch.rand(64, generator=g) - 0.5) * 0.2).to(dev)
+    w1 = ((torch.rand(64, 64, 3, 3, generator=g) - 0.5) * 0.1).to(dev)
+    dy = (torch.rand(n, h // 2, w // 2, 64, generator=g) - 0.5).to(torch.bfloat16).to(dev)
+    d0 = L.ConvDesc(L.BF16, n, h, w, 3, 64, 3, 3, 1, 1, 0)
+    d1 = L.ConvDesc(L.BF16, n, h, w, 64, 64, 3, 3, 2, 1, 0)
+    wf1 = torch.empty(lib.dsr_conv_packed_elems(C.byref(d1), 0), dtype=torch.bfloat16, device=dev)
+    wd1 = torch.empty(lib.dsr_conv_packed_elems(C.byref(d1), 1), dtype=torch.bfloat16, device=dev)
+    L.check(lib.dsr_conv_pack_weight(C.byref(d1), w1.data_ptr(), wf1.data_ptr(), wd1.data_ptr(), st))
+    dw = torch.empty(64, 3, 3, 3, dtype=torch.float32, device=dev)
+    db = torch.empty(64, dtype=torch.float32, device=dev)
+    da0 = torch.empty(n, h, w, 64, dtype=torch.bfloat16, device=dev)
+    wsz = lib.dsr_conv_dgrad_first_bwd_workspace(C.byref(d1))
+    ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+    wsz2 = lib.dsr_conv_dgrad_workspace(C.byref(d1))
+    ws2 = torch.empty(max(wsz2, 16), dtype=torch.uint8, device=dev)
+    wsz3 = lib.dsr_conv_first_bwd_workspace(C.byref(d0))
+    ws3 = torch.empty(wsz3, dtype=torch.uint8, device=dev)
+
+    def fused():
+        L.check(lib.dsr_conv_dgrad_first_bwd(C.byref(d0), C.byref(d1), dy.data_ptr(), wd1.data_ptr(), xg.data_ptr(), w0.data_ptr(),
+                                             b0.data_ptr(), L.ACT_LEAKY, 0.2, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), wsz, st))
+
+    def dgrad():
+        L.check(lib.dsr_conv_dgrad(C.byref(d1), dy.data_ptr(), wd1.data_ptr(), da0.data_ptr(), ws2.data_ptr(), wsz2, st))
+
+    def first_bwd():
+        L.check(lib.dsr_conv_first_bwd_recompute(C.byref(d0), xg.data_ptr(), da0.data_ptr(), w0.data_ptr(), b0.data_ptr(), L.ACT_LEAKY,
+                                                 0.2, dw.data_ptr(), db.data_ptr(), ws3.data_ptr(), wsz3, st))
+
+    def both():
+        dgrad()
+        first_bwd()
+
+    print(f"backward of the first two layers, batch {n}, {h}x{w}:")
+    for name, fn in (("one launch  (dsr_conv_dgrad_first_bwd)", fused), ("dsr_conv_dgrad (stride 2)", dgrad),
+                     ("dsr_conv_first_bwd_recompute", first_bwd), ("two launches", both)):
+        print(f"  {name:42s} {timeit(fn):7.3f} ms")
+
+
 if __name__ == "__main__":
-    main()
+    if "backward" in sys.argv[1:]:
+        backward()
+    else:
+        main()
