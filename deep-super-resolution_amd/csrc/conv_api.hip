@@ -788,3 +788,37 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
   }
   return "conv_wgrad_kernel";
 }
+
+// ---- input gradient of a 3x3 stride-2 layer + the BatchNorm-backward sums of the layer in front (conv_dgrad_s2_kernel<BN>)
+static bool dgrad_bn_ok(const dsr_conv_desc* d) {
+  return d && (d->dtype == DSR_BF16 || d->dtype == DSR_F16) && d->N > 0 && d->Cin % 8 == 0 &&
+         dsr_dgrad_s2_bn_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->H, d->W, r8(d->Cin), r8(d->Cout), d->N);
+}
+extern "C" int dsr_conv_dgrad_bn_supported(const dsr_conv_desc* d) { return dgrad_bn_ok(d) ? 1 : 0; }
+extern "C" int dsr_conv_dgrad_bn_rows(const dsr_conv_desc* d) {
+  return d ? dsr_dgrad_s2_blocks(d->N, d->H, d->W, r8(d->Cin)) : 0;
+}
+extern "C" int dsr_conv_dgrad_bn(const dsr_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* bn_y,
+                                 const float* bn_scale, const float* bn_shift, int act, float slope, float* partial,
+                                 dsr_stream_t s) {
+  if (!dgrad_bn_ok(d)) return dsr_fail(DSR_E_UNSUPPORTED, "conv_dgrad_bn: unsupported layer");
+  if (!dy || !w_dgrad || !dx || !bn_y || !bn_scale || !bn_shift || !partial) return dsr_fail(DSR_E_ARG, "conv_dgrad_bn: null pointer");
+  if (act != DSR_ACT_NONE && act != DSR_ACT_LEAKY) return dsr_fail(DSR_E_ARG, "conv_dgrad_bn: activation %d (LeakyReLU or none)", act);
+  DgradS2Args q;
+  memset(&q, 0, sizeof(q));
+  q.dy = dy;
+  q.w = w_dgrad;
+  q.dx = dx;
+  q.H = d->H;
+  q.W = d->W;
+  q.CinP = r8(d->Cin);
+  q.CoutP = r8(d->Cout);
+  q.bn_y = bn_y;
+  q.bn_scale = bn_scale;
+  q.bn_shift = bn_shift;
+  q.bn_partial = partial;
+  q.bn_act = act;
+  q.bn_slope = slope;
+  dsr_launch_dgrad_s2(q, d->N, d->dtype, s);
+  return dsr_launch_status("dsr_conv_dgrad_bn");
+}

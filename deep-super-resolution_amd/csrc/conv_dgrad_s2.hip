@@ -43,6 +43,17 @@ constexpr int FB_W0 = FB_HALO + 3 * FB_ROWP;      // the first layer's weights [
 constexpr int FB_B0 = FB_W0 + 64 * 64;            // its fp32 bias
 constexpr int FB_LDS = FB_B0 + 64 * 4;            // 163,072 of 163,840 bytes
 static_assert(FB_ROW3 + FB_ROWP <= S2_STAGE && FB_LDS <= 160 * 1024, "LDS budget of the fused form");
+// BN (BatchNorm-backward sums in the epilogue): ring of six 8 KB slots (512 threads x 16 B) for the y pieces
+constexpr int BN_SLOT = 512 * 16;
+constexpr int BN_HI = S2_LDS;                     // slots 0..2 above the two stages
+constexpr int BN_LO = 256 * S2_CSTRIDE;           // slots 3..5 behind the C tile in the consumed stage
+constexpr int BN_AFF = BN_HI + 3 * BN_SLOT;       // this block's 64 channels of scale | shift (fp32)
+constexpr int BN_ACC = BN_AFF + 2 * 64 * 4;       // per wave: [2][64] sums
+constexpr int BN_LDS = BN_ACC + 8 * 128 * 4;      // 160,256 bytes
+static_assert(BN_LO + 3 * BN_SLOT <= S2_STAGE && BN_LDS <= 160 * 1024, "LDS budget of the BatchNorm form");
+// pieces k = 4 class + it of a tile; the wait for piece k leaves the operations issued after it in flight: the pieces
+// k+1 .. k+5 (as far as they exist) and the stores of the pieces k-5 .. k-1
+__host__ __device__ constexpr int bn_wait(int k) { return (k < 5 ? k : 5) + (15 - k < 5 ? 15 - k : 5); }
 
 // class c = 2*ph + pw, shift s = 2*sy + sx: the tap (kh*3 + kw) that shift s feeds into class c, or -1
 __host__ __device__ constexpr int s2_tap(int c, int s) {
@@ -54,6 +65,11 @@ __host__ __device__ constexpr int s2_tap(int c, int s) {
 }
 }   // namespace
 
+__device__ __forceinline__ void s2_load8(const float* src, int c0, float (&dst)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(src + c0), b = *reinterpret_cast<const f32x4*>(src + c0 + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dst[i] = a[i], dst[4 + i] = b[i];
+}
 __device__ __forceinline__ s16x4 s2_tr_read(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
@@ -81,8 +97,20 @@ __device__ unsigned long long s2_stamps[256][12];
 //   * D[co][col] += sum_p g[p][co] B[p][col] by MFMA with the pixel as contraction index (transposing LDS reads), column 27
 //     of B being 1 (the bias gradient); one partial [64][32] per wave pair and block, folded by first_bwd_finalize_kernel.
 // Only for 64 -> 64 channels (one K block, one channel block) and dY rows that are whole tiles (OW % 256 == 0).
-template <int DT, bool FB>
+//
+// MODE 2 (BN, dsr_conv_dgrad_bn: dx is the gradient of a BatchNorm + LeakyReLU output, discriminator.py:14-19): the launch also
+// forms the BatchNorm backward's two per-channel sums, sum g and sum g y with g = dx * act'(scale y + shift), y being the
+// raw conv output of the layer in front -- the sums the separate reduce pass (bn_act_bwd_reduce_kernel) reads dx AND y for.
+// The thread that stores a 16-byte vector of dx also fetches the same vector of y: by LDS-DMA into a ring of six thread-
+// private 16-byte slots (three above the stages, three in the consumed stage), six pieces ahead of their use, so that the
+// tile's 128 KB of y are in flight while the epilogue runs and no register holds them; every wait is a counted vmcnt (the
+// pieces and the output stores retire in order).  Sums: 16 accumulators per thread and tile, folded per wave into LDS rows
+// that only that wave touches (deterministic), one partial row [3][CinP] per block at the end.
+// Only for tiles that are whole rows of ONE image (256 % OW == 0 or OW % 256 == 0, OH OW % 256 == 0) and gridDim.x % (CinP / 64)
+// == 0 (a block then keeps its 64-channel slice for all its tiles).
+template <int DT, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args a) {
+  constexpr bool FB = MODE == 1, BN = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,6 +142,23 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
     }
     if (tid < 64) reinterpret_cast<float*>(smem + FB_B0)[tid] = a.b0 ? a.b0[tid] : 0.f;
   }
+  [[maybe_unused]] const BufSrd ysr = make_srd(a.bn_y, a.dx_bytes);
+  [[maybe_unused]] const int cib0 = xcd_remap(blockIdx.x, gridDim.x) % a.ci_blocks;     // BN: the block's channel slice (all its tiles)
+  if constexpr (BN) {
+    if (tid < 128) reinterpret_cast<float*>(smem + BN_AFF)[tid] = (tid < 64 ? a.bn_scale : a.bn_shift)[cib0 * 64 + (tid & 63)];
+    for (int i = tid; i < 8 * 128; i += 512) reinterpret_cast<float*>(smem + BN_ACC)[i] = 0.f;
+  }
+  // BN: byte offset in dx (and in y) of this thread's vector `it` of output-parity class (0, 0) of the tile at dY pixel m0_ --
+  // tiles are whole rows of one image, so a pixel of the tile is (p / OW, p % OW) away from the tile's first; class (ph, pw)
+  // adds the scalar (ph W + pw) CinP 2
+  [[maybe_unused]] auto bn_base = [&](int m0_, int cib_, int it, int tio) {
+    const int n = fd_div(a.fd_ghw, m0_), rem = m0_ - n * (a.OH * a.OW);
+    const int gy0 = fd_div(a.fd_gw, rem), gx0 = rem - gy0 * a.OW;
+    const int idx = tio + 512 * it, p = idx >> 3, ch = idx & 7;
+    const int pr = fd_div(a.fd_gw, p), pc = p - pr * a.OW;
+    return (unsigned)((((n * a.H + 2 * (gy0 + pr)) * a.W + 2 * (gx0 + pc)) * a.CinP + cib_ * 64 + ch * 8) * 2);
+  };
+  [[maybe_unused]] auto bn_class = [&](int c) { return (unsigned)((((c >> 1) * a.W + (c & 1)) * a.CinP) * 2); };
   // FB: one 64-pixel piece `pc` of image halo row `row` of the tile whose dx origin is (n, Y0, X0) -> 1 KB at dst
   [[maybe_unused]] auto halo_piece = [&](int n, int Y0, int X0, int row, int pc, unsigned char* dst) {
     int lo = lane;
@@ -221,6 +266,14 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
           } else if (tn < ntiles) {                           // (uniform) next tile's first step
             setup(tn);
             dma_issue(3, 0, cur ^ 1);
+          }
+          if constexpr (BN) {
+            if (last) {                                       // the first three y pieces of THIS tile, behind the last DMA
+              int tio = tid;
+              asm volatile("" : "+v"(tio));   // (opaque: the offsets are recomputed here, not kept in registers across the tile loop)
+#pragma unroll
+              for (int k = 0; k < 3; ++k) lds_dma16(ysr, smem + BN_HI + k * BN_SLOT + wave * 1024, bn_base(m0, cib, k, tio));
+            }
           }
           if constexpr (FB) {
             if (s == 2) {
@@ -417,6 +470,22 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
         S2_ADD(10, (tf2 - tf1) + (tf4 - tf3) + (tf6 - tf5));
       }
     } else {
+    // BN: per-thread sums of this tile (8 channels: the thread's vector column), the slice's scale / shift
+    [[maybe_unused]] float sg[8], sgy[8], bsc[8], bsh[8];
+    [[maybe_unused]] unsigned boff[4];
+    [[maybe_unused]] int tio = tid;
+    if constexpr (BN) {
+      asm volatile("" : "+v"(tio));
+#pragma unroll
+      for (int it = 0; it < 4; ++it) boff[it] = bn_base(m0, cib, it, tio);
+      lds_dma16(ysr, sC + BN_LO + wave * 1024, boff[3]);                                     // pieces 3, 4, 5 (that stage is free now)
+      lds_dma16(ysr, sC + BN_LO + BN_SLOT + wave * 1024, boff[0] + bn_class(1));
+      lds_dma16(ysr, sC + BN_LO + 2 * BN_SLOT + wave * 1024, boff[1] + bn_class(1));
+      s2_load8(reinterpret_cast<const float*>(smem + BN_AFF), (tio & 7) * 8, bsc);
+      s2_load8(reinterpret_cast<const float*>(smem + BN_AFF) + 64, (tio & 7) * 8, bsh);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sg[k] = sgy[k] = 0.f;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int ph = c >> 1, pw = c & 1;
@@ -433,6 +502,38 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
+        if constexpr (BN) {
+          const int kq = 4 * c + it;                  // piece kq: wait for it (counted: everything issued after it stays in flight)
+          unsigned char* slot = (kq % 6) < 3 ? smem + BN_HI + (kq % 6) * BN_SLOT : sC + BN_LO + (kq % 6 - 3) * BN_SLOT;
+          const int idx = tio + 512 * it;
+          const int row = idx >> 3, ch = idx & 7;
+          const U4 v = *reinterpret_cast<const U4*>(sC + row * S2_CSTRIDE + ch * 16);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bn_wait(kq)) : "memory");
+          const U4 yv = *reinterpret_cast<const U4*>(slot + tio * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v, dxr, boff[it] + bn_class(c), 0, 0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my 16 bytes of the slot are in registers: it may be refilled
+          if (kq + 6 < 16) lds_dma16(ysr, slot + wave * 1024, boff[(kq + 6) & 3] + bn_class((kq + 6) >> 2));
+          // g = d * act'(scale y + shift); sum g, sum g y -- two channels per instruction where the ISA has packed fp32 forms
+          typedef __attribute__((ext_vector_type(2))) float f32x2;
+          float d[8], f[8];
+          unpack8<DT>(v, d);
+          unpack8<DT>(yv, f);
+          const bool leaky = a.bn_act == DSR_ACT_LEAKY;
+          const f32x2 sl2 = {a.bn_slope, a.bn_slope};
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) {
+            const f32x2 f2 = {f[k], f[k + 1]}, d2 = {d[k], d[k + 1]};
+            const f32x2 z2 = f2 * f32x2{bsc[k], bsc[k + 1]} + f32x2{bsh[k], bsh[k + 1]};
+            const f32x2 ds2 = d2 * sl2;
+            f32x2 g2;
+            g2.x = (leaky && z2.x < 0.f) ? ds2.x : d2.x;
+            g2.y = (leaky && z2.y < 0.f) ? ds2.y : d2.y;
+            f32x2 a2 = {sg[k], sg[k + 1]}, b2 = {sgy[k], sgy[k + 1]};
+            a2 += g2;
+            b2 += g2 * f2;
+            sg[k] = a2.x, sg[k + 1] = a2.y, sgy[k] = b2.x, sgy[k + 1] = b2.y;
+          }
+        } else {
         const int idx = tid + 512 * it;              // 256 rows x 8 chunks
         const int row = idx >> 3, ch = idx & 7;
         const int m = m0 + row;
@@ -444,15 +545,47 @@ __global__ __launch_bounds__(512, 2) void conv_dgrad_s2_kernel(const DgradS2Args
         const unsigned off = (unsigned)((((n * a.H + 2 * gy + ph) * a.W + 2 * gx + pw) * a.CinP + cib * 64 + ch * 8) * 2);
         const U4 v = *reinterpret_cast<const U4*>(sC + row * S2_CSTRIDE + ch * 16);
         __builtin_amdgcn_raw_buffer_store_b128(v, dxr, m < a.M ? off : OOB, 0, 0);
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                           // the C tile has been read: the next class may overwrite it
       asm volatile("" ::: "memory");
     }
+    if constexpr (BN) {
+      // fold the tile's sums: over the 8 lanes of this wave that share a vector column (lane & 7), then into the wave's LDS rows
+      float* wacc = reinterpret_cast<float*>(smem + BN_ACC) + wave * 128;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float x = sg[k], y2 = sgy[k];
+        x += __shfl_xor(x, 8, 64);
+        y2 += __shfl_xor(y2, 8, 64);
+        x += __shfl_xor(x, 16, 64);
+        y2 += __shfl_xor(y2, 16, 64);
+        x += __shfl_xor(x, 32, 64);
+        y2 += __shfl_xor(y2, 32, 64);
+        if (lane < 8) {
+          wacc[lane * 8 + k] += x;
+          wacc[64 + lane * 8 + k] += y2;
+        }
+      }
+    }
     }
     S2_STAMP(te1);
     S2_ADD(4, te1 - te0);
     S2_ADD(5, 1);
+  }
+  if constexpr (BN) {
+    __syncthreads();
+    const float* wacc = reinterpret_cast<const float*>(smem + BN_ACC);
+    for (int j = tid; j < 3 * a.CinP; j += 512) {            // one row [3][CinP] per block: its slice of the two sums, zeros elsewhere
+      const int which = j / a.CinP, cc = j - which * a.CinP;
+      float sum = 0.f;
+      if (which < 2 && (cc >> 6) == cib0) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sum += wacc[w * 128 + which * 64 + (cc & 63)];       // fixed order
+      }
+      a.bn_partial[(size_t)blockIdx.x * 3 * a.CinP + j] = sum;
+    }
   }
   if constexpr (FB) {
     // partial[2 block + wm][co][32]: lane (g, r16) holds D[co = 16 wn + 4 g + j][col = 16 nf + r16]
@@ -497,24 +630,46 @@ void dsr_launch_dgrad_s2(DgradS2Args& a, int N, int dtype, hipStream_t st) {
   const int blocks = ntiles < 256 ? ntiles : 256;          // persistent: one 8-wave block per CU (128 KB of LDS each)
   static LdsOptIn optin[4];   // more than 64 KB of dynamic LDS needs the opt-in, once per kernel and device (not a stream operation)
   if (a.img) {                // the first-layer backward in the epilogue (dsr_conv_dgrad_first_bwd checked the shape)
-    optin[2].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_BF16, true>, FB_LDS);
-    optin[3].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_F16, true>, FB_LDS);
+    optin[2].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_BF16, 1>, FB_LDS);
+    optin[3].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_F16, 1>, FB_LDS);
     if (dtype == DSR_DTYPE_BF16)
-      hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_BF16, true>), dim3(blocks), dim3(512), FB_LDS, st, a);
+      hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_BF16, 1>), dim3(blocks), dim3(512), FB_LDS, st, a);
     else
-      hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_F16, true>), dim3(blocks), dim3(512), FB_LDS, st, a);
+      hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_F16, 1>), dim3(blocks), dim3(512), FB_LDS, st, a);
     return;
   }
-  optin[0].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_BF16, false>, S2_LDS);
-  optin[1].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_F16, false>, S2_LDS);
+  if (a.bn_y) {               // BatchNorm-backward sums in the epilogue (dsr_conv_dgrad_bn checked the shape)
+    static LdsOptIn optin_bn[2];
+    optin_bn[0].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_BF16, 2>, BN_LDS);
+    optin_bn[1].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_F16, 2>, BN_LDS);
+    if (dtype == DSR_DTYPE_BF16)
+      hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_BF16, 2>), dim3(blocks), dim3(512), BN_LDS, st, a);
+    else
+      hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_F16, 2>), dim3(blocks), dim3(512), BN_LDS, st, a);
+    return;
+  }
+  optin[0].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_BF16, 0>, S2_LDS);
+  optin[1].ensure((const void*)conv_dgrad_s2_kernel<DSR_DTYPE_F16, 0>, S2_LDS);
   if (dtype == DSR_DTYPE_BF16)
-    hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_BF16, false>), dim3(blocks), dim3(512), S2_LDS, st, a);
+    hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_BF16, 0>), dim3(blocks), dim3(512), S2_LDS, st, a);
   else
-    hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_F16, false>), dim3(blocks), dim3(512), S2_LDS, st, a);
+    hipLaunchKernelGGL((conv_dgrad_s2_kernel<DSR_DTYPE_F16, 0>), dim3(blocks), dim3(512), S2_LDS, st, a);
 }
 
 // blocks of a launch (the fused form writes two partial rows per block)
 int dsr_dgrad_s2_blocks(int N, int H, int W, int CinP) {
   const long long ntiles = (((long long)N * (H / 2) * (W / 2) + S2_BM - 1) / S2_BM) * (CinP / 64);
   return (int)(ntiles < 256 ? ntiles : 256);
+}
+
+// the BatchNorm form: tiles are whole rows of one image, a block keeps its 64-channel slice
+bool dsr_dgrad_s2_bn_supported(int KH, int KW, int stride, int pad, int pad_mode, int H, int W, int CinP, int CoutP, int N) {
+  const char* e = getenv("DSR_DGRAD_BN");            // tuning switch, read per call: 0 = never
+  if (e && e[0] == '0') return false;
+  if (KH != 3 || KW != 3 || stride != 2 || pad != 1 || pad_mode != DSR_PAD_ZERO) return false;
+  if ((H & 1) || (W & 1) || CinP % 64 || CoutP % 64) return false;
+  const int OH = H / 2, OW = W / 2;
+  if (!(S2_BM % OW == 0 || OW % S2_BM == 0) || (OH * OW) % S2_BM != 0) return false;
+  if (dsr_dgrad_s2_blocks(N, H, W, CinP) % (CinP / 64) != 0) return false;
+  return (long long)N * H * W * CinP * 2 < (1ll << 31);
 }

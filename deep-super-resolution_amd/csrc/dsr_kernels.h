@@ -237,8 +237,16 @@ struct DgradS2Args {
   unsigned img_bytes;
   int Cin0, act0;
   float slope0;
+  // BatchNorm-backward sums in the epilogue (dsr_conv_dgrad_bn; bn_y == nullptr: none)
+  const void* bn_y;       // [N][H][W][CinP] raw conv output of the layer whose BatchNorm + activation output dx is the gradient of
+  const float* bn_scale;  // [CinP] its affine map (gamma * rstd, beta - mean * gamma * rstd)
+  const float* bn_shift;
+  float* bn_partial;      // [blocks][3][CinP]: sum g, sum g*y, 0
+  int bn_act;
+  float bn_slope;
 };
 int dsr_dgrad_s2_blocks(int N, int H, int W, int CinP);
+bool dsr_dgrad_s2_bn_supported(int KH, int KW, int stride, int pad, int pad_mode, int H, int W, int CinP, int CoutP, int N);
 bool dsr_dgrad_s2_supported(int KH, int KW, int stride, int pad, int pad_mode, int H, int W, int CinP, int CoutP, int N);
 void dsr_launch_dgrad_s2(DgradS2Args& a, int N, int dtype, hipStream_t st);
 

@@ -334,14 +334,26 @@ class ActLink:
         self.act, self.slope, self.premasked = act, float(slope), False
 
 
-def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape, weight=None, addend=None, in_link=None):
+def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape, weight=None, addend=None, in_link=None, bn_link=None):
     """dx (+ `addend`: the gradient that reaches x along a skip path, summed in the dgrad epilogue where the kernel can; or
-    `in_link`: the activation that produced x, whose backward mask is folded into the dgrad stores where the kernel can) and dw."""
+    `in_link`: the activation that produced x, whose backward mask is folded into the dgrad stores where the kernel can; or
+    `bn_link`: x is the output of a BatchNorm + LeakyReLU layer that left its raw conv output and affine map there -- the
+    dgrad launch then also forms that layer's BatchNorm-backward sums, dsr_conv_dgrad_bn, and leaves the partial rows in
+    the link) and dw."""
     lib = _lib.lib()
     dx = dw = None
     if need_dx:
         dx = torch.empty_like(x)
-        if in_link is not None and addend is None and lib.dsr_conv_dgrad_masked_supported(C.byref(desc)):
+        if (bn_link is not None and "y" in bn_link and addend is None and DGRAD_BN and bn_link["act"] in (ACT_NONE, ACT_LEAKY)
+                and bn_link["y"].shape == x.shape and lib.dsr_conv_dgrad_bn_supported(C.byref(desc))):
+            rows = lib.dsr_conv_dgrad_bn_rows(C.byref(desc))
+            cp = x.shape[-1]
+            part = torch.empty((rows + _scr()) * 3 * cp, dtype=torch.float32, device=x.device)
+            check(_timed("dgrad", desc, lambda: lib.dsr_conv_dgrad_bn(
+                C.byref(desc), _ptr(dy), _ptr(wd), _ptr(dx), _ptr(bn_link["y"]), _ptr(bn_link["scale"]), _ptr(bn_link["shift"]),
+                bn_link["act"], float(bn_link["slope"]), _ptr(part), _stream()), name="conv_dgrad_s2_kernel<bn>"))
+            bn_link["part"] = (part, rows, dx.data_ptr())
+        elif in_link is not None and addend is None and lib.dsr_conv_dgrad_masked_supported(C.byref(desc)):
             check(_timed("dgrad", desc, lambda: lib.dsr_conv_dgrad_masked(C.byref(desc), _ptr(dy), _ptr(wd), _ptr(x), in_link.act,
                                                                             in_link.slope, _ptr(dx), _stream())))
             in_link.premasked = True
@@ -550,6 +562,7 @@ class ConvAct(torch.autograd.Function):
 
 
 FIRST2_BACKWARD = os.environ.get("DSR_FIRST2_BACKWARD", "1") != "0"   # 0: the first two layers' backward as separate launches
+DGRAD_BN = os.environ.get("DSR_DGRAD_BN_LINK", "1") != "0"             # 0: BatchNorm-backward sums always by their own reduce pass
 
 
 def _first2_backward(ctx, desc, x, dy, wd):
@@ -685,6 +698,12 @@ class ConvBNAct(torch.autograd.Function):
         check(lib.dsr_pw_bn_act_fwd(_dt(x), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), count, cp, act,
                                     float(cfg.get("slope", 0.0)), _ptr(prelu), _stream()))
         ctx.desc, ctx.cfg, ctx.act, ctx.train, ctx.count = desc, cfg, act, train, count
+        bol = cfg.get("bn_out_link")
+        if bol is not None:
+            # the layer that consumes `out` may form this layer's BatchNorm-backward sums inside its input-gradient launch
+            bol.clear()
+            if train and residual is None and prelu is None and not cfg.get("infer", False):
+                bol.update(y=y, scale=scale, shift=shift, act=act, slope=float(cfg.get("slope", 0.0)))
         ctx.wshape = tuple(weight.shape)
         ctx.weight_ref = weight
         ctx.has_res = residual is not None
@@ -715,11 +734,19 @@ class ConvBNAct(torch.autograd.Function):
         dgamma = torch.empty(cout, dtype=torch.float32, device=dev)
         dbeta = torch.empty(cout, dtype=torch.float32, device=dev)
         dprelu = torch.empty(1, dtype=torch.float32, device=dev) if prelu is not None else None
-        blocks, rpb = _bn_bwd_blocks(p, ctx.act)
-        part = torch.empty((blocks + _scr()) * 3 * cp, dtype=torch.float32, device=dev)
-        check(lib.dsr_pw_bn_act_bwd_reduce(_dt(x), _ptr(dout), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean),
-                                           _ptr(rstd), p, cp, blocks, rpb, ctx.act, slope, _ptr(prelu), _ptr(part),
-                                           _stream()))
+        bol = ctx.cfg.get("bn_out_link")
+        got = bol.pop("part", None) if bol is not None else None
+        if bol is not None:
+            bol.clear()
+        if got is not None and got[2] == dout.data_ptr():
+            # the launch that produced `dout` (the next layer's input gradient, dsr_conv_dgrad_bn) formed the two sums already
+            part, blocks = got[0], got[1]
+        else:
+            blocks, rpb = _bn_bwd_blocks(p, ctx.act)
+            part = torch.empty((blocks + _scr()) * 3 * cp, dtype=torch.float32, device=dev)
+            check(lib.dsr_pw_bn_act_bwd_reduce(_dt(x), _ptr(dout), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean),
+                                               _ptr(rstd), p, cp, blocks, rpb, ctx.act, slope, _ptr(prelu), _ptr(part),
+                                               _stream()))
         check(lib.dsr_pw_bn_bwd_finalize(_ptr(part), blocks, cout, cp, float(p), _ptr(mean), _ptr(rstd), _ptr(dgamma),
                                          _ptr(dbeta), _ptr(dprelu), _ptr(c1), _ptr(c2), _stream()))
         dy = torch.empty_like(y)
@@ -734,7 +761,7 @@ class ConvBNAct(torch.autograd.Function):
             _, dw = _conv_backward(desc, x, dy, wd, False, ctx.needs_input_grad[1], ctx.wshape, getattr(ctx, "weight_ref", None))
         else:
             dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape,
-                                     getattr(ctx, "weight_ref", None), dcarry)
+                                     getattr(ctx, "weight_ref", None), dcarry, bn_link=ctx.cfg.get("bn_in_link"))
         db = None
         if ctx.has_bias and not ctx.train:
             # a bias in front of a train-mode BatchNorm has an analytically zero gradient (the reference holds ~1e-9

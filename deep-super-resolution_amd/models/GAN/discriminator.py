@@ -21,10 +21,14 @@ class DiscriminatorConvBlock(nn.Module):
         self.stride = stride
         self.compute_dtype = torch.bfloat16
 
-    def _block(self, x, first2=None):
+    def _block(self, x, first2=None, bn_out_link=None, bn_in_link=None):
         cfg = dict(stride=self.stride, pad=1, act=F.ACT_LEAKY, slope=0.2, train=self.training)
         if first2 is not None:
             cfg["first2"] = first2
+        if bn_out_link is not None:
+            cfg["bn_out_link"] = bn_out_link
+        if bn_in_link is not None:
+            cfg["bn_in_link"] = bn_in_link
         return F.ConvBNAct.apply(x, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias,
                                  self.bn1.running_mean, self.bn1.running_var, self.bn1.num_batches_tracked,
                                  None, None, cfg)                                           # discriminator.py:15-17
@@ -75,8 +79,13 @@ class Discriminator(nn.Module):
         link = {} if fused else None
         z = F.ConvAct.apply(xi, self.conv.weight, self.conv.bias, None,
                             dict(stride=1, pad=1, act=F.ACT_LEAKY, slope=0.2, defer=fused, first2_link=link))  # :60-61
+        # (`bnl`: a stride-2 block's input-gradient launch also forms the BatchNorm-backward sums of the block in front of it,
+        #  dsr_conv_dgrad_bn: that block leaves its raw conv output and affine map in the link, and finds the partial rows there)
+        nb = len(self.convblocks)
+        bnl = [{} if (i + 1 < nb and self.convblocks[i + 1].stride == 2) else None for i in range(nb)]
         for i, blk in enumerate(self.convblocks):                                             # :63
-            z = blk._block(z, (xi, self.conv.weight, self.conv.bias, 0.2, link) if (fused and i == 0) else None)
+            z = blk._block(z, (xi, self.conv.weight, self.conv.bias, 0.2, link) if (fused and i == 0) else None,
+                           bn_out_link=bnl[i], bn_in_link=bnl[i - 1] if i > 0 else None)
         return z
 
     def head(self, z):

@@ -107,6 +107,17 @@ int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const void* dout, 
 int dsr_conv_first_bwd_recompute(const dsr_conv_desc* d, const void* x, const void* dout, const float* w, const float* bias,
                                  int act, float slope, float* dw, float* db, void* workspace, size_t ws_bytes, dsr_stream_t s);
 
+/* dsr_conv_dgrad of a 3x3 stride-2 layer (discriminator.py:31,33,35) whose input is the output of BatchNorm + LeakyReLU
+ * (:14-19), with the two per-channel sums the BatchNorm backward of that layer needs formed in the same launch: partial gets
+ * dsr_conv_dgrad_bn_rows(d) rows of [3][r8(Cin)] = (sum g, sum g*y, 0) with g = dx * act'(scale*y + shift) -- what
+ * dsr_pw_bn_act_bwd_reduce would write after reading dx and y (bn_y: that layer's raw conv output, same shape as dx) once more;
+ * feed them to dsr_pw_bn_bwd_finalize.  act: LeakyReLU or none.  _supported(): H, W even, tiles of 256 gradient pixels that
+ * are whole rows of one image, one 64-channel slice per block. */
+int dsr_conv_dgrad_bn_supported(const dsr_conv_desc* d);
+int dsr_conv_dgrad_bn_rows(const dsr_conv_desc* d);
+int dsr_conv_dgrad_bn(const dsr_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* bn_y,
+                      const float* bn_scale, const float* bn_shift, int act, float slope, float* partial, dsr_stream_t s);
+
 /* The backward counterpart of dsr_conv_first2_fwd for a step that needs no image gradient (the discriminator's own update,
  * train_GAN.py:47-56): the input gradient of the stride-2 layer d1 (discriminator.py:29) and the whole backward of the image
  * layer d0 under it (:25-27: activation mask, bias gradient, weight gradient) in ONE launch.  The gradient of the 64-channel

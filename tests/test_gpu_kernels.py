@@ -482,6 +482,75 @@ def test_first_layer_fused_backward(dev, n, h, w, actn):
     assert rel_err(dw_f, dw_u) < 5e-3 and rel_err(db_f, db_u) < 5e-3
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,actn", [(2, 32, 32, 128, 128, "leaky"), (3, 64, 64, 256, 256, "leaky"), (1, 4, 512, 64, 128, "none"),
+                                                  (40, 64, 64, 128, 64, "leaky"), (2, 32, 32, 512, 512, "leaky")])
+def test_conv_dgrad_with_batchnorm_backward_sums(dev, n, h, w, cin, cout, actn):
+    """dsr_conv_dgrad_bn -- the input gradient of a 3x3 stride-2 layer (discriminator.py:31,33,35) that also forms the two sums
+    the BatchNorm backward of the layer in front needs (sum g, sum g*y with g = dx * LeakyReLU'(scale*y + shift)) while dx is
+    on its way out -- against dsr_conv_dgrad (dx must agree BIT FOR BIT: the same kernel body), against the separate reduce
+    pass it replaces (dsr_pw_bn_act_bwd_reduce -> dsr_pw_bn_bwd_finalize: dgamma, dbeta, c1, c2 from both sets of partial rows)
+    and against float64 sums over the stored dx.  One to eight 64-channel slices, tiles of 16 rows down to a row segment,
+    more tiles than persistent blocks (batch 40: 320 tiles on 256 blocks, blocks with one and with two tiles)."""
+    import ctypes as C
+    L = P("_lib")
+    F = P("functional")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    act = dict(leaky=F.ACT_LEAKY, none=F.ACT_NONE)[actn]
+    g = torch.Generator(device="cpu").manual_seed(cin + h)
+    oh, ow = h // 2, w // 2
+    dy = bfr(torch.rand(n, cout, oh, ow, generator=g) - 0.5)
+    wt = bfr((torch.rand(cout, cin, 3, 3, generator=g) - 0.5) * 0.1)
+    y = bfr(torch.randn(n, cin, h, w, generator=g))
+    scale = torch.rand(cin, generator=g) + 0.5
+    scale[::3] *= -1
+    shift = (torch.rand(cin, generator=g) - 0.5)
+    mean = torch.rand(cin, generator=g) - 0.5
+    rstd = torch.rand(cin, generator=g) + 0.5
+    d = L.ConvDesc(L.BF16, n, h, w, cin, cout, 3, 3, 2, 1, 0)
+    assert lib.dsr_conv_dgrad_bn_supported(C.byref(d)) == 1
+    wf = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 0), dtype=torch.bfloat16, device=dev)
+    wd = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 1), dtype=torch.bfloat16, device=dev)
+    L.check(lib.dsr_conv_pack_weight(C.byref(d), wt.to(dev).data_ptr(), wf.data_ptr(), wd.data_ptr(), st))
+    dyg, yg = to_nhwc(dy, cout).to(dev), to_nhwc(y, cin).to(dev)
+    scg, shg, mg, rg = scale.to(dev), shift.to(dev), mean.to(dev), rstd.to(dev)
+    scr = lib.dsr_pw_scratch_rows()
+    # ---- one launch
+    rows = lib.dsr_conv_dgrad_bn_rows(C.byref(d))
+    part = torch.full(((rows + scr) * 3 * cin,), float("nan"), dtype=torch.float32, device=dev)
+    dx_f = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
+    L.check(lib.dsr_conv_dgrad_bn(C.byref(d), dyg.data_ptr(), wd.data_ptr(), dx_f.data_ptr(), yg.data_ptr(), scg.data_ptr(),
+                                  shg.data_ptr(), act, 0.2, part.data_ptr(), st))
+    # ---- dgrad, then the reduce pass
+    dx_t = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
+    wsz = lib.dsr_conv_dgrad_workspace(C.byref(d))
+    ws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=dev)
+    L.check(lib.dsr_conv_dgrad(C.byref(d), dyg.data_ptr(), wd.data_ptr(), dx_t.data_ptr(), ws.data_ptr(), wsz, st))
+    p = n * h * w
+    blocks, rpb = F._bn_bwd_blocks(p, act)
+    part_t = torch.empty((blocks + scr) * 3 * cin, dtype=torch.float32, device=dev)
+    L.check(lib.dsr_pw_bn_act_bwd_reduce(L.BF16, dx_t.data_ptr(), yg.data_ptr(), scg.data_ptr(), shg.data_ptr(), mg.data_ptr(),
+                                         rg.data_ptr(), p, cin, blocks, rpb, act, 0.2, None, part_t.data_ptr(), st))
+    outs = []
+    for pt, nb in ((part, rows), (part_t, blocks)):
+        o = [torch.empty(cin, dtype=torch.float32, device=dev) for _ in range(4)]
+        L.check(lib.dsr_pw_bn_bwd_finalize(pt.data_ptr(), nb, cin, cin, float(p), mg.data_ptr(), rg.data_ptr(), o[0].data_ptr(),
+                                           o[1].data_ptr(), None, o[2].data_ptr(), o[3].data_ptr(), st))
+        outs.append([t.cpu().double() for t in o])
+    torch.cuda.synchronize()
+    assert torch.equal(dx_f, dx_t)
+    rowsum = part[:rows * 3 * cin].view(rows, 3, cin).cpu().double().sum(0)
+    assert torch.isfinite(rowsum).all() and float(rowsum[2].abs().max()) == 0.0
+    dxd, yd = from_nhwc(dx_t.cpu(), cin).double(), y.double()
+    z = (y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))                 # fp32, as the kernels form it
+    gref = dxd * (torch.where(z < 0, 0.2, 1.0).double() if actn == "leaky" else 1.0)
+    sg_ref, sgy_ref = gref.sum(dim=(0, 2, 3)), (gref * yd).sum(dim=(0, 2, 3))
+    tol_g, tol_gy = 2e-5 * float(gref.abs().sum(dim=(0, 2, 3)).max()), 2e-5 * float((gref * yd).abs().sum(dim=(0, 2, 3)).max())
+    assert float((rowsum[0] - sg_ref).abs().max()) < tol_g and float((rowsum[1] - sgy_ref).abs().max()) < tol_gy
+    for a_, b_ in zip(*outs):                       # dgamma, dbeta, c1, c2: the two sets of partial rows through the same finalize
+        assert float((a_ - b_).abs().max()) < 1e-4 * float(b_.abs().max()) + 1e-6
+
+
 @pytest.mark.parametrize("n,h,w,cin,actn", [(2, 6, 512, 3, "leaky"), (1, 4, 1024, 3, "relu"), (3, 2, 512, 1, "leaky"), (130, 4, 512, 3, "leaky")])
 def test_first_two_layers_fused_backward(dev, n, h, w, cin, actn):
     """dsr_conv_dgrad_first_bwd -- the input gradient of discriminator.py:29 (Conv2d(64,64,3,2,1)) and the whole backward of

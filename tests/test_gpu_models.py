@@ -325,6 +325,45 @@ def test_discriminator_fused_first_two_layers_equal_two_launches(dev, need_dx, m
         assert rel_err(ra[k], rb[k]) < 2e-3, k
 
 
+def test_discriminator_batchnorm_sums_in_the_next_layers_input_gradient(dev, monkeypatch):
+    """A stride-2 block's input-gradient launch also forms the BatchNorm-backward sums of the block in front of it
+    (dsr_conv_dgrad_bn through the link Discriminator.features sets up); functional.DGRAD_BN off runs the separate reduce pass.
+    Same module, weights and batch at 128 x 128 (blocks 1 and 3 qualify: tiles of whole rows of one image; block 5's 8 x 8
+    gradient map does not and keeps its reduce pass): identical output, the same launches taken as expected, every gradient
+    equal to fp32 summation order."""
+    Dm = P("models.GAN.discriminator")
+    F = P("functional")
+    hw = (128, 128)
+    n = 2
+    sd = filler.fill_state_dict(gan.template(gan.discriminator_shapes(hw)))
+    x = filler.tensor("in:disc_bn", (n, 3, hw[0], hw[1]))
+    probe = filler.tensor("probe:disc_bn", (n, 1)).to(dev)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(F, "DGRAD_BN", on)
+        d = Dm.Discriminator(hw)
+        d.load_state_dict(sd)
+        d.to(dev).train()
+        xg = x.to(dev).requires_grad_(True)
+        F.KERNEL_LOG = []
+        try:
+            y = d(xg)
+            (y * probe).sum().backward()
+            torch.cuda.synchronize()
+            names = [e[4] for e in F.KERNEL_LOG]
+        finally:
+            F.KERNEL_LOG = None
+        assert sum("kernel<bn>" in nm for nm in names) == (2 if on else 0), names
+        res[on] = (y.detach().clone(), {k: p.grad.clone() for k, p in d.named_parameters() if p.grad is not None}, xg.grad.clone())
+    (ya, ga, dxa), (yb, gb, dxb) = res[True], res[False]
+    assert torch.equal(ya, yb) and set(ga) == set(gb)
+    for k in ga:
+        assert torch.isfinite(ga[k]).all() and rel_err(ga[k], gb[k]) < 2e-3, (k, rel_err(ga[k], gb[k]))
+    # (the image gradient passes through bf16 tensors: a last-bit change in a BatchNorm coefficient flips single roundings, one
+    #  bf16 ulp = 0.4 % of an element)
+    assert rel_err(dxa, dxb) < 1e-2 and cos(dxa, dxb) > 0.99999
+
+
 def test_discriminator_fused_backward_of_first_two_layers(dev, monkeypatch):
     """An image that needs no gradient (the discriminator's own update, train_GAN.py:47-56): ConvBNAct.backward of the second
     layer runs its input gradient AND the image layer's whole backward as one launch (dsr_conv_dgrad_first_bwd) and hands the
