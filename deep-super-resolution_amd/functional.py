@@ -214,10 +214,19 @@ class batched_wgrad:
 
     MAX_PROBLEMS = 256           # kMaxBatchProblems of dsr_conv_wgrad_batched: larger groups are split in flush()
 
-    def __init__(self, enabled=True):
+    def __init__(self, enabled=True, early_stream=None, early_every=0):
+        """early_stream / early_every: every `early_every` collected problems are launched AT ONCE on `early_stream` (behind an
+        event of the stream the backward pass runs on) instead of at the exit: the grouped launch of a long chain of layers
+        (the generator's trunk) then runs beside the rest of that chain's input gradients instead of after them.  Only for
+        weights used once inside the block; the exit waits for the early launches."""
         self.enabled = enabled
         self.items = {}          # id(weight) -> [weight, returned tensor, alias of it, [(desc, x, dy), ...], [extra addends]]
         self.unbatched = set()   # id(weight) of weights that already returned a REAL gradient inside this block
+        self.early_stream = early_stream if early_every > 0 else None
+        self.early_every = int(early_every)
+        self.done = []           # entries whose launch is already on early_stream
+        self.early_ids = set()
+        self.reused = set()      # ... and which were used again afterwards
 
     def __enter__(self):
         global _wgrad_batch
@@ -232,7 +241,10 @@ class batched_wgrad:
             _wgrad_batch = None
             if et is None:
                 self.flush()
+                self._finish_early()
             else:
+                if self.done:
+                    torch.cuda.current_stream().wait_stream(self.early_stream)
                 # backward raised: the launch never ran, so a .grad that autograd already pointed at one of the placeholder
                 # tensors holds uninitialised memory -- drop it rather than leave garbage behind
                 for weight, _, alias, _, _ in self.items.values():
@@ -241,6 +253,9 @@ class batched_wgrad:
                         weight.grad = None
             self.items = {}
             self.unbatched = set()
+            self.done = []
+            self.early_ids = set()
+            self.reused = set()
         return False
 
     def add(self, weight, desc, x, dy, wshape):
@@ -253,7 +268,41 @@ class batched_wgrad:
         # (the alias shares dw's storage through a tensor object of its own: autograd takes over a gradient only while
         # nobody else holds the very tensor it was handed)
         self.items[id(weight)] = [weight, None, dw.detach(), [(desc, x, dy)], []]
+        if self.early_stream is not None and sum(len(e[3]) for e in self.items.values()) >= self.early_every:
+            self._launch_early()
         return dw
+
+    def batchable(self, weight):
+        """False for a weight whose gradient launch is already under way on the early stream: a second use of it inside the
+        block is computed on its own, after that launch (the caller's stream is made to wait for it here)."""
+        if id(weight) in self.early_ids:
+            torch.cuda.current_stream().wait_stream(self.early_stream)
+            self.reused.add(id(weight))      # autograd now sums a real tensor onto the finished placeholder: .grad is that sum
+            return False
+        return id(weight) not in self.unbatched
+
+    def _launch_early(self):
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)                       # every dy collected so far was enqueued on `cur` before this point
+        self.early_stream.wait_event(ev)
+        ents = list(self.items.values())
+        with torch.cuda.stream(self.early_stream):
+            self._launch(ents)
+        for weight, _, alias, uses, _ in ents:
+            alias.record_stream(self.early_stream)
+            for _, x, dy in uses:            # (allocated on `cur`: not to be handed out again before the early launch has read them)
+                x.record_stream(self.early_stream)
+                dy.record_stream(self.early_stream)
+            self.early_ids.add(id(weight))
+        self.done.extend(ents)
+        self.items = {}
+
+    def _finish_early(self):
+        if not self.done:
+            return
+        torch.cuda.current_stream().wait_stream(self.early_stream)
+        self._settle([e for e in self.done if id(e[0]) not in self.reused])
 
     def add_unbatchable(self, weight, dw):
         """A use of `weight` that the grouped launch cannot take (other stride / padding ...), computed at once as `dw`.  If an
@@ -270,8 +319,12 @@ class batched_wgrad:
     def flush(self):
         if not self.items:
             return
-        lib = _lib.lib()
         ents = list(self.items.values())
+        self._launch(ents)
+        self._settle(ents)
+
+    def _launch(self, ents):
+        lib = _lib.lib()
         by_dtype = {}
         for ent in ents:
             by_dtype.setdefault(ent[3][0][0].dtype, []).append(ent)
@@ -307,6 +360,9 @@ class batched_wgrad:
                 e1.record()
                 KERNEL_LOG.append(("wgrad_batch", [(d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad) for d in descs],
                                    e0, e1, "conv_wgrad_dma_batch_kernel"))
+
+    @staticmethod
+    def _settle(ents):
         for weight, _, alias, uses, extra in ents:
             for e in extra:                               # contributions of uses the grouped launch could not take
                 alias.add_(e)
@@ -370,7 +426,7 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, weight_shape, weight=None,
     if addend is not None:
         dx = addend if dx is None else dx + addend
     if (need_dw and _wgrad_batch is not None and weight is not None and weight.grad is None
-            and id(weight) not in _wgrad_batch.unbatched                      # (an earlier use returned a real gradient)
+            and _wgrad_batch.batchable(weight)                                # (an earlier use returned a real gradient / was launched early)
             and not getattr(weight, "_post_accumulate_grad_hooks", None)      # (a hook would read the gradient at once)
             and lib.dsr_conv_wgrad_batchable(C.byref(desc))):
         return dx, _wgrad_batch.add(weight, desc, x, dy, weight_shape)

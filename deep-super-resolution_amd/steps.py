@@ -4,6 +4,8 @@ gen_l1_step : BASELINE config 2 (generator-only x4, L1, Adam) -- defined by SURV
 gan_step    : train_GAN.py:38-71 (do_epoch): D step, then G step with the detached adversarial term.
 dip_step    : DIP.py:47-95 closure + utils/DIP.py:33-40 Adam iteration.
 """
+import os
+
 import torch
 
 from . import functional as F
@@ -22,10 +24,9 @@ def gen_l1_step(gen, opt, lr_patches, hr_patches):
 _side_streams = {}
 
 
-def _side_stream(device):
-    key = (device.type, device.index)
+def _side_stream(device, which="d"):
+    key = (device.type, device.index, which)
     if key not in _side_streams:
-        import os
         # DSR_SIDE_PRIORITY (tuning switch): HIP stream priority of the D-half stream, 0 = default, -1 = high
         _side_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("DSR_SIDE_PRIORITY", "0")))
     return _side_streams[key]
@@ -55,7 +56,6 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
     # two outputs are bit-identical and only the BatchNorm running statistics notice the second call.  One forward
     # (with the autograd graph the G step needs) + a double running-stat update is exactly equivalent.
     if batch_wgrad is None:
-        import os
         batch_wgrad = os.environ.get("DSR_WGRAD_BATCH", "1") != "0"    # tuning switch: 0 = one weight-gradient launch per layer
     main = torch.cuda.current_stream(hr_patches.device)
     side = _side_stream(hr_patches.device) if overlap else main
@@ -110,7 +110,12 @@ def gan_step(gen, disc, perceptual, opt_g, opt_d, lr_patches, hr_patches, sync_g
     content = perceptual.content(fake, hr_patches, hr_feat)      # the only term of :59 with a gradient path
     opt_g.zero_grad()                                            # :62
     _mark("main: VGG content loss forward done", main)
-    with F.batched_wgrad(batch_wgrad):                           # the generator's 35 3x3 layers: one grouped launch
+    # the generator's 35 3x3 layers: grouped launches.  With `overlap` every DSR_WGRAD_EARLY (default 16, 0 = off) collected
+    # layers go out at once on a third stream: the generator half is the longer chain of the two, its backward is one long
+    # dependency chain of input gradients, and the weight gradients hang off that chain -- launched at the exit they ran alone
+    # at the end of the step (the D half has finished by then); launched as they become ready they run beside the chain
+    early = int(os.environ.get("DSR_WGRAD_EARLY", "16")) if (overlap and batch_wgrad) else 0
+    with F.batched_wgrad(batch_wgrad, early_stream=_side_stream(hr_patches.device, "wgrad") if early else None, early_every=early):
         content.backward()                                       # :63 (d adversarial / d generator == 0, see above)
     _mark("main: G backward done", main)
     if sync_g is not None:

@@ -1160,6 +1160,44 @@ def test_batched_wgrad_leaves_existing_grad_and_exceptions_alone(dev):
     assert F._wgrad_batch is None
 
 
+def test_batched_wgrad_early_launches_on_another_stream(dev):
+    """functional.batched_wgrad(early_stream=, early_every=): every few collected layers are launched at once on another stream
+    (behind an event of the backward pass's stream) instead of at the exit -- steps.gan_step does that for the generator half.
+    The same gradients as the exit launch up to fp32 summation order (another split of the pixels over blocks), for a group
+    size that divides the layer count, one that does not, and one larger than it (nothing early); a weight used a second time
+    after its early launch (the same generator applied twice in one graph) is still summed correctly."""
+    Gm, F = P("models.GAN.generator"), P("functional")
+    gsd = filler.fill_state_dict(gan.template(gan.generator_shapes(4, 3)))
+    x = filler.tensor("in:bw_early", (2, 3, 16, 16), 0.5, 0.5).to(dev)
+    hr = filler.tensor("in:bw_early_hr", (2, 3, 64, 64)).to(dev)
+    side = torch.cuda.Stream()
+
+    def grads(every, twice):
+        g = Gm.Generator(4, 3)
+        g.load_state_dict(gsd)
+        g.to(dev).train()
+        with F.batched_wgrad(True, early_stream=side if every else None, early_every=every) as ctx:
+            loss = F.l1_loss(g(x), hr)
+            if twice:
+                loss = F.add_losses(loss, F.l1_loss(g(x * 0.5), hr))
+            loss.backward()
+            launched_early = len(ctx.done)
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in g.named_parameters() if p.grad is not None}, launched_early
+
+    for twice in (False, True):
+        ref, n0 = grads(0, twice)
+        assert n0 == 0
+        for every in (2, 3, 100):
+            got, n_early = grads(every, twice)
+            assert (n_early > 0) == (every < 100), (every, n_early)
+            assert set(got) == set(ref)
+            for k in ref:
+                a, b = ref[k].double(), got[k].double()
+                assert torch.isfinite(b).all() and float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-12, (twice, every, k)
+    assert F._wgrad_batch is None
+
+
 def test_batched_wgrad_weight_with_a_batchable_and_an_unbatchable_use(dev):
     """One 3x3 weight applied twice in a graph, once at stride 1 (the grouped launch takes it) and once at stride 2 (it does
     not), in both orders of the backward pass: inside functional.batched_wgrad the first use's placeholder must not be summed
