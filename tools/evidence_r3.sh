@@ -11,6 +11,11 @@ for w in gen_l1_x4 infer_x8 dip_x2; do timeout -k 10 200 python3 bench.py --work
 timeout -k 10 300 python3 tools/microbench_conv.py > $O/microbench_conv.txt 2>&1
 timeout -k 10 100 python3 tools/microbench_dense_adam.py > $O/microbench_dense_adam.txt 2>&1
 timeout -k 10 100 python3 tools/microbench_first2.py > $O/microbench_first2.txt 2>&1
+timeout -k 10 100 python3 tools/microbench_first2.py backward >> $O/microbench_first2.txt 2>&1
+timeout -k 10 100 python3 tools/microbench_dgrad_bn.py > $O/microbench_dgrad_bn.txt 2>&1
+if [ -x tools/_bin/diag_dgrad_s2 ]; then
+  { timeout -k 10 60 tools/_bin/diag_dgrad_s2 32 512 512 64 64 0; timeout -k 10 60 tools/_bin/diag_dgrad_s2 32 512 512 64 64 1; timeout -k 10 60 tools/_bin/diag_dgrad_s2 32 256 256 128 128 0; } > $O/diag_dgrad_s2.txt 2>&1
+fi
 timeout -k 10 100 python3 tools/microbench_first_bwd.py > $O/microbench_first_bwd.txt 2>&1
 timeout -k 10 100 python3 tools/trace_step.py > $O/trace_step.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
