@@ -57,6 +57,9 @@ SIGNATURES = {
     "dsr_conv_first2_stats_rows": (_I, [_DESC]),
     "dsr_conv_first2_fwd": (_I, [_DESC, _DESC, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P]),
     "dsr_conv_first_bwd_recompute": (_I, [_DESC, _P, _P, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
+    "dsr_conv_dgrad_ps_supported": (_I, [_DESC]),
+    "dsr_conv_dgrad_ps_rows": (_I, [_DESC]),
+    "dsr_conv_dgrad_ps": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),
     "dsr_conv_dgrad_bn_supported": (_I, [_DESC]),
     "dsr_conv_dgrad_bn_rows": (_I, [_DESC]),
     "dsr_conv_dgrad_bn": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P]),
@@ -129,7 +132,7 @@ _lib = None
 # bench.py's roofline leg: a list here makes every launching entry point record (name, start_event, end_event) on the
 # stream it launches on (torch's current stream), so that the GPU-busy share of a step can be told from launch gaps.
 LAUNCH_LOG = None
-_NO_LAUNCH = ("dsr_last_error", "dsr_abi_version", "dsr_conv_dgrad_bn_supported", "dsr_conv_dgrad_bn_rows", "dsr_conv_dgrad_first_bwd_supported", "dsr_conv_dgrad_first_bwd_workspace", "dsr_conv_kernel_name", "dsr_conv_wgrad_batchable", "dsr_conv_wgrad_batched_workspace", "dsr_conv_dgrad_add_supported", "dsr_conv_dgrad_masked_supported", "dsr_conv_fwd_affine_supported",
+_NO_LAUNCH = ("dsr_last_error", "dsr_abi_version", "dsr_conv_dgrad_ps_supported", "dsr_conv_dgrad_ps_rows", "dsr_conv_dgrad_bn_supported", "dsr_conv_dgrad_bn_rows", "dsr_conv_dgrad_first_bwd_supported", "dsr_conv_dgrad_first_bwd_workspace", "dsr_conv_kernel_name", "dsr_conv_wgrad_batchable", "dsr_conv_wgrad_batched_workspace", "dsr_conv_dgrad_add_supported", "dsr_conv_dgrad_masked_supported", "dsr_conv_fwd_affine_supported",
               "dsr_conv_first2_supported", "dsr_conv_first2_stats_rows", "dsr_conv_first_bwd_supported", "dsr_conv_first_bwd_workspace", "dsr_conv_out_size", "dsr_conv_stats_rows",
               "dsr_conv_packed_elems", "dsr_conv_dgrad_workspace", "dsr_conv_wgrad_workspace", "dsr_pw_scratch_rows",
               "dsr_pw_reduce_blocks", "dsr_linear_fwd_workspace", "dsr_ssim_blocks")

@@ -822,3 +822,20 @@ extern "C" int dsr_conv_dgrad_bn(const dsr_conv_desc* d, const void* dy, const v
   dsr_launch_dgrad_s2(q, d->N, d->dtype, s);
   return dsr_launch_status("dsr_conv_dgrad_bn");
 }
+
+// ---- input gradient of the 9x9 64 -> 3 tail (generator.py:78) with the backward of the PixelShuffle + PReLU in front of it
+// (generator.py:37-39) in its epilogue (conv_dgrad_toeplitz9_kernel<PS>)
+static bool dgrad_ps_ok(const dsr_conv_desc* d) {
+  const char* e = getenv("DSR_DGRAD_PS");            // tuning switch, read per call: 0 = never
+  if (e && e[0] == '0') return false;
+  return d && is_tail9(d) && !(d->H & 1) && !(d->W & 1) && d->H >= 2 && d->W >= 2;
+}
+extern "C" int dsr_conv_dgrad_ps_supported(const dsr_conv_desc* d) { return dgrad_ps_ok(d) ? 1 : 0; }
+extern "C" int dsr_conv_dgrad_ps_rows(const dsr_conv_desc* d) { return d ? dsr_dgrad_toeplitz_ps_blocks(d->N, d->H, d->W) : 0; }
+extern "C" int dsr_conv_dgrad_ps(const dsr_conv_desc* d, const void* dy, const void* w_dgrad, const void* act_out,
+                                 const float* prelu, void* dyu, float* partial, dsr_stream_t s) {
+  if (!dgrad_ps_ok(d)) return dsr_fail(DSR_E_UNSUPPORTED, "conv_dgrad_ps: unsupported layer");
+  if (!dy || !w_dgrad || !act_out || !prelu || !dyu || !partial) return dsr_fail(DSR_E_ARG, "conv_dgrad_ps: null pointer");
+  dsr_launch_dgrad_toeplitz(dy, w_dgrad, nullptr, d->N, d->H, d->W, d->dtype, s, act_out, prelu, dyu, partial);
+  return dsr_launch_status("dsr_conv_dgrad_ps");
+}

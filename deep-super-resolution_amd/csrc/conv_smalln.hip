@@ -729,17 +729,32 @@ struct Tail9DgradArgs {
   int N, H, W;
   int strips, bands, rows_per_band;
   unsigned dy_bytes, dx_bytes;
+  // PS (dsr_conv_dgrad_ps): the input x of this convolution is PReLU(PixelShuffle(2)(conv)) (generator.py:37-39 in front of :78)
+  const void* act_out;   // x itself [N][H][W][64]: the activation OUTPUT whose sign selects the PReLU branch
+  const float* prelu;    // the PReLU weight (one value)
+  void* dyu;             // [N][H/2][W/2][256]: gradient of the shuffle conv's output, channel 4c + 2i + j <- pixel (2h+i, 2w+j)
+  float* ps_partial;     // [blocks][2][256]: column sums of dyu (that conv's bias gradient) | PReLU weight gradient terms
 };
 
-template <int DT>
+// PS = true: the backward of the activation in front of this convolution rides in the epilogue.  dx = the gradient of
+// PReLU(PixelShuffle(conv)) is never written: the accumulators are multiplied by the PReLU derivative (sign of the activation
+// output, whose 64-pixel row strip arrives by LDS-DMA one row ahead), the PReLU-weight gradient terms d * o / slope are summed
+// per thread, two consecutive rows of masked gradient are kept in the wave's slab and leave UN-SHUFFLED -- dyu[h][w][4c + 2i + j]
+// from pixel (2h + i, 2w + j), sixteen-byte vectors of (2 channels x 4 sub-pixels) assembled from four 4-byte slab reads --
+// with their column sums (the shuffle conv's bias gradient) accumulated on the way out.  That is all of act_bwd_kernel's
+// PixelShuffle branch, which otherwise reads dx and the activation and writes dyu: three passes over a 1.07 GB tensor at
+// config 3.  Bands start and end on even rows.
+template <int DT, bool PS>
 __global__ __launch_bounds__(256, 2) void conv_dgrad_toeplitz9_kernel(const Tail9DgradArgs a) {
-  constexpr int SLOTS = 12, A_IMG = 64 * 64, D_RAW = 128 * 16, C_SLAB = 16 * 128;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SLOTS * A_IMG + 2 * D_RAW + 4 * C_SLAB];
+  constexpr int SLOTS = PS ? 10 : 12, A_IMG = 64 * 64, D_RAW = 128 * 16, C_SLAB = 16 * 128;
+  constexpr int NSLAB = PS ? 2 : 1, O_STRIP = 64 * 128;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SLOTS * A_IMG + 2 * D_RAW + 4 * NSLAB * C_SLAB + (PS ? 2 * O_STRIP : 0)];
   unsigned char* sA = smem;
   unsigned char* sD = smem + SLOTS * A_IMG;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l16 = lane & 15;
-  unsigned char* sC = sD + 2 * D_RAW + wave * C_SLAB;
+  unsigned char* sC = sD + 2 * D_RAW + wave * NSLAB * C_SLAB;
+  [[maybe_unused]] unsigned char* sO = sD + 2 * D_RAW + 4 * NSLAB * C_SLAB;
   const int item = blockIdx.x;
   const int n = item / (a.strips * a.bands);
   const int rem = item - n * a.strips * a.bands;
@@ -749,7 +764,6 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_toeplitz9_kernel(const Tail
   const int rb1 = rb0 + a.rows_per_band < a.H ? rb0 + a.rows_per_band : a.H;
   const int H = a.H, W = a.W;
   const unsigned short* __restrict__ Wg = reinterpret_cast<const unsigned short*>(a.w);
-  unsigned short* __restrict__ DX = reinterpret_cast<unsigned short*>(a.dx);
 
   // ---- weights -> registers: fw[kh][mf] = A'[m = ci 16mf + l16][k = 8g..8g+7], k = 3kw + co (k >= 27: zero)
   U4 fw[9][4];
@@ -776,16 +790,28 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_toeplitz9_kernel(const Tail
   }
   __syncthreads();
 
-  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
+  // (LDS-DMA by inline asm, dsr_common.h: the compiler's wait-count pass then knows nothing of it and every wait below is explicit)
+  const BufSrd yrsrc = make_srd(a.dy, a.dy_bytes);
+  [[maybe_unused]] const BufSrd orsrc = make_srd(a.act_out, a.dx_bytes);
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  typedef __attribute__((address_space(3))) void* lds_ptr;
   auto dma_raw = [&](int yd) {                           // raw dy strip of row yd: columns p0-4 .. p0+67 (waves 0 and 1)
     if (wave < 2) {
       const int q = 64 * wave + lane;
       const int x = p0 - 4 + q;
       const bool ok = q < 72 && (unsigned)yd < (unsigned)H && (unsigned)x < (unsigned)W;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, (lds_ptr)(sD + (yd & 1) * D_RAW + wave * 1024), 16,
-                                               ok ? (unsigned)((((n * H + yd) * W + x) * 8) * 2) : OOB, 0, 0, 0);
+      lds_dma16(yrsrc, sD + (yd & 1) * D_RAW + wave * 1024, ok ? (unsigned)((((n * H + yd) * W + x) * 8) * 2) : OOB);
+    }
+  };
+  // PS: the activation-output strip of row yo (64 pixels x 128 B): a wave fetches its own 16 pixels (two pieces of 8 pixels x 8
+  // chunks); slot (pixel, c) receives channel chunk c ^ (pixel & 7), so that the 8-byte reads below spread over the banks
+  [[maybe_unused]] auto dma_out = [&](int yo) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int px = 16 * wave + 8 * u + (lane >> 3), c = lane & 7;
+      const int x = p0 + px;
+      const bool ok = yo < H && x < W;
+      lds_dma16(orsrc, sO + (yo & 1) * O_STRIP + (16 * wave + 8 * u) * 128,
+                ok ? (unsigned)((((n * H + yo) * W + x) * 64 + ((c ^ (px & 7)) << 3)) * 2) : OOB);
     }
   };
   auto build_A = [&](int y) {                            // A_y[p][k] = dy[y][p0 + p - kw + 4][co]; one 16-byte chunk per thread
@@ -810,21 +836,39 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_toeplitz9_kernel(const Tail
   const int px = 16 * wave + l16;                        // this lane's pixel (B' operand column) inside the strip
   const int b_off = px * 64 + ((g ^ ((px >> 2) & 3)) << 4);
   const int r_start = rb0 - 9;
-  // output rows leave by range-checked buffer stores: exactly two per thread and row, so that "at most two outstanding" at
-  // the top of the next row means the raw strip requested BEFORE them has landed (vmcnt retires in order) while the stores
-  // themselves stay in flight -- a vmcnt(0) there exposed the full store latency on every one of the block's rows
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(a.dx, 0, a.dx_bytes, 0x00020000);
+  // output rows leave by range-checked buffer stores: exactly two per thread and row (PS: four per thread and row PAIR), so
+  // that "at most that many outstanding" at the top of the next row means the strips requested BEFORE them have landed (vmcnt
+  // retires in order) while the stores themselves stay in flight -- a vmcnt(0) there exposed the full store latency per row
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(PS ? a.dyu : a.dx, 0, a.dx_bytes, 0x00020000);
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   const unsigned sC_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)sC);
+  [[maybe_unused]] float sb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] float sp = 0.f;
+  [[maybe_unused]] float slope = 0.f, inv_slope = 0.f, poison = 0.f;
+  if constexpr (PS) {
+    slope = a.prelu[0];
+    inv_slope = 1.f / slope;
+    poison = !(slope > 0.f) ? __uint_as_float(0x7fc00000u) : 0.f;      // (see act_bwd_kernel: a slope that crossed zero poisons the launch)
+  }
   dma_raw(r_start + 5);
+  if constexpr (PS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler's own wait for `slope` would come later, behind DMAs it cannot see)
   for (int r = r_start; r < rb1; ++r) {
-    if (r > rb0)                                         // (uniform) the previous iteration stored a row
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (PS) {
+      if (r > rb0 && !(r & 1))                           // (uniform) the previous iteration (an odd row) issued four stores
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (r > rb0)                                       // (uniform) the previous iteration stored a row
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (r + 1 < rb1) dma_raw(r + 6);
+    if constexpr (PS)
+      if (r + 1 >= rb0 && r + 1 < rb1) dma_out(r + 1);
     build_A(r + 5);
     if (r >= rb0) {
       f32x4 acc[4];
@@ -839,6 +883,28 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_toeplitz9_kernel(const Tail
           for (int mf = 0; mf < 4; ++mf) acc[mf] = mfma16<DT>(fw[kh][mf], fb, acc[mf]);
         }
       }
+      if constexpr (PS) {
+        // acc[mf][j] = d(channel 16 mf + 4 g + j, pixel l16): g = d * PReLU'(o), PReLU-weight terms d * o / slope where o < 0
+        const unsigned char* so = sO + (r & 1) * O_STRIP + px * 128 + (g & 1) * 8;
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+          const uint2 ov = *reinterpret_cast<const uint2*>(so + (((2 * mf + (g >> 1)) ^ (px & 7)) << 4));
+          const float o[4] = {h2f<DT>((unsigned short)(ov.x & 0xffff)), h2f<DT>((unsigned short)(ov.x >> 16)),
+                              h2f<DT>((unsigned short)(ov.y & 0xffff)), h2f<DT>((unsigned short)(ov.y >> 16))};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float d = acc[mf][j];
+            sp = __builtin_fmaf(d, __builtin_fminf(o[j], 0.f), sp);          // (times 1 / slope once, at the end)
+            acc[mf][j] = o[j] >= 0.f ? d : d * slope;
+          }
+        }
+        if (poison != 0.f) {                             // (uniform, never in a healthy run)
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[mf][j] += poison;
+        }
+      }
       // acc[mf][j] = dIn[ci = 16mf + 4g + j][pixel l16 of this wave] -> slab -> 16-byte NHWC stores
 #pragma unroll
       for (int mf = 0; mf < 4; ++mf) {
@@ -850,9 +916,45 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_toeplitz9_kernel(const Tail
         // (the raw strip requested at the top of this row would be waited for here, every row)
         typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
         const u32x2 hv = {h.x, h.y};
-        asm volatile("ds_write_b64 %0, %1" ::"v"(sC_lds + (unsigned)(l16 * 128 + ((c16 ^ (l16 & 7)) << 4) + (g & 1) * 8)), "v"(hv) : "memory");
+        asm volatile("ds_write_b64 %0, %1" ::"v"(sC_lds + (unsigned)((PS ? (r & 1) * C_SLAB : 0) + l16 * 128 + ((c16 ^ (l16 & 7)) << 4) + (g & 1) * 8)), "v"(hv) : "memory");
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the slab is this wave's own: no barrier)
+      if constexpr (PS) {
+        if (r & 1) {
+          // rows r - 1 (i = 0) and r (i = 1) of this wave's 16 pixels -> 8 low-resolution pixels x 256 channels, un-shuffled:
+          // vector q = lane + 64 v: pixel w' = q >> 5, channels 8u .. 8u+7 (u = q & 31) = shuffle channels 2u, 2u + 1 at the
+          // four sub-pixels (element k: channel 2u + (k >> 2), i = (k >> 1) & 1, j = k & 1)
+          int lo = lane;
+          asm volatile("" : "+v"(lo));      // (opaque: the slab addresses below are re-derived per row pair -- hoisted out of the row
+          const int u = lo & 31;            //  loop they were spilled to scratch, and every reload waited for the strips in flight)
+          const int LH = H >> 1, LW = W >> 1;
+          const int hh = (r - 1) >> 1;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int wq = (lo >> 5) + 2 * v;
+            unsigned rd[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const int pp = 2 * wq + j;
+                rd[i][j] = *reinterpret_cast<const unsigned*>(sC + i * C_SLAB + pp * 128 + (((u >> 2) ^ (pp & 7)) << 4) + (u & 3) * 4);
+              }
+            u32x4 o4;
+            o4.x = (rd[0][0] & 0xffffu) | (rd[0][1] << 16);
+            o4.y = (rd[1][0] & 0xffffu) | (rd[1][1] << 16);
+            o4.z = (rd[0][0] >> 16) | (rd[0][1] & 0xffff0000u);
+            o4.w = (rd[1][0] >> 16) | (rd[1][1] & 0xffff0000u);
+            const int xw = (p0 >> 1) + 8 * wave + wq;
+            float f[8];
+            unpack8<DT>(__builtin_bit_cast(U4, o4), f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sb[k] += xw < LW ? f[k] : 0.f;     // (a strip may reach past the right edge of the image)
+            const unsigned off = (unsigned)((((n * LH + hh) * LW + xw) * 256 + 8 * u) * 2);
+            __builtin_amdgcn_raw_buffer_store_b128(o4, xrsrc, xw < LW ? off : OOB, 0, 0);
+          }
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int idx = lane + 64 * i;
@@ -862,31 +964,77 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_toeplitz9_kernel(const Tail
         const unsigned off = (unsigned)((((n * H + r) * W + x) * 64 + c16 * 8) * 2);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xrsrc, x < W ? off : OOB, 0, 0);
       }
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  if constexpr (PS) {
+    // one partial row [2][256] per block: column sums of dyu over the 8 threads that share a vector column (lane & 31: the two
+    // half-waves of four waves), and the block's sum of PReLU-weight terms in column 0 of the second slice (fixed order)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(sA);           // [8][256] + [256]
+    const int part = 2 * wave + (lane >> 5), u = lane & 31;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[part * 256 + 8 * u + k] = sb[k];
+    red[8 * 256 + tid] = sp * inv_slope + poison;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += red[q * 256 + tid];
+    a.ps_partial[((size_t)blockIdx.x * 2 + 0) * 256 + tid] = s;
+    float t = 0.f;
+    if (tid == 0)
+      for (int q = 0; q < 256; ++q) t += red[8 * 256 + q];
+    a.ps_partial[((size_t)blockIdx.x * 2 + 1) * 256 + tid] = t;
+  }
 }
 
-void dsr_launch_dgrad_toeplitz(const void* dy, const void* w_dgrad, void* dx, int N, int H, int W, int dtype, hipStream_t st) {
+// plan of the 9x9 input gradient: returns the number of blocks (= partial rows of the PS form)
+static int dgrad_toeplitz_plan(int N, int H, int W, bool ps, Tail9DgradArgs* a) {
+  WgradTileArgs t;
+  memset(&t, 0, sizeof(t));
+  dsr_wgrad_toeplitz_plan(N, H, W, &t);
+  a->strips = t.tiles_x;
+  a->rows_per_band = t.tiles_per_block;
+  if (ps && (a->rows_per_band & 1)) ++a->rows_per_band;        // bands start and end on even rows (H is even)
+  a->bands = (H + a->rows_per_band - 1) / a->rows_per_band;
+  return N * a->strips * a->bands;
+}
+int dsr_dgrad_toeplitz_ps_blocks(int N, int H, int W) {
   Tail9DgradArgs a;
+  return dgrad_toeplitz_plan(N, H, W, true, &a);
+}
+
+void dsr_launch_dgrad_toeplitz(const void* dy, const void* w_dgrad, void* dx, int N, int H, int W, int dtype, hipStream_t st,
+                               const void* act_out, const float* prelu, void* dyu, float* ps_partial) {
+  Tail9DgradArgs a;
+  memset(&a, 0, sizeof(a));
   a.dy = dy;
   a.w = w_dgrad;
   a.dx = dx;
   a.N = N;
   a.H = H;
   a.W = W;
-  WgradTileArgs t;
-  memset(&t, 0, sizeof(t));
-  dsr_wgrad_toeplitz_plan(N, H, W, &t);
-  a.strips = t.tiles_x;
-  a.bands = t.tiles_y;
-  a.rows_per_band = t.tiles_per_block;
+  const bool ps = act_out != nullptr;
+  const int blocks = dgrad_toeplitz_plan(N, H, W, ps, &a);
   a.dy_bytes = (unsigned)((size_t)N * H * W * 16);
-  a.dx_bytes = (unsigned)((size_t)N * H * W * 128);      // (check_desc refuses tensors of 2 GiB or more)
+  a.dx_bytes = (unsigned)((size_t)N * H * W * 128);      // (check_desc refuses tensors of 2 GiB or more; dyu is the same size)
+  a.act_out = act_out;
+  a.prelu = prelu;
+  a.dyu = dyu;
+  a.ps_partial = ps_partial;
+  if (ps) {
+    static LdsOptIn optin[2];   // 76 KB of static LDS: above the 64 KB default
+    if (dtype == DSR_DTYPE_BF16)
+      hipLaunchKernelGGL((conv_dgrad_toeplitz9_kernel<DSR_DTYPE_BF16, true>), dim3(blocks), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((conv_dgrad_toeplitz9_kernel<DSR_DTYPE_F16, true>), dim3(blocks), dim3(256), 0, st, a);
+    return;
+  }
   if (dtype == DSR_DTYPE_BF16)
-    hipLaunchKernelGGL((conv_dgrad_toeplitz9_kernel<DSR_DTYPE_BF16>), dim3(t.ntiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_dgrad_toeplitz9_kernel<DSR_DTYPE_BF16, false>), dim3(blocks), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((conv_dgrad_toeplitz9_kernel<DSR_DTYPE_F16>), dim3(t.ntiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_dgrad_toeplitz9_kernel<DSR_DTYPE_F16, false>), dim3(blocks), dim3(256), 0, st, a);
 }
 
 void dsr_launch_wgrad_toeplitz(const WgradTileArgs& a, int dtype, hipStream_t st) {

@@ -159,7 +159,10 @@ void dsr_launch_wgrad_tile(const WgradTileArgs& a, int KH, int stride, int ychun
 // 9x9 stride-1 "same" convolution with <= 3 output channels and 64 input channels (conv_smalln.hip)
 int dsr_wgrad_toeplitz_plan(int N, int H, int W, WgradTileArgs* a);
 void dsr_launch_wgrad_toeplitz(const WgradTileArgs& a, int dtype, hipStream_t st);
-void dsr_launch_dgrad_toeplitz(const void* dy, const void* w_dgrad, void* dx, int N, int H, int W, int dtype, hipStream_t st);
+void dsr_launch_dgrad_toeplitz(const void* dy, const void* w_dgrad, void* dx, int N, int H, int W, int dtype, hipStream_t st,
+                               const void* act_out = nullptr, const float* prelu = nullptr, void* dyu = nullptr,
+                               float* ps_partial = nullptr);      // act_out != nullptr: the PixelShuffle-PReLU backward in the epilogue
+int dsr_dgrad_toeplitz_ps_blocks(int N, int H, int W);
 int dsr_wgrad_taps_plan(int KH, int KW, int stride, int N, int OH, int OW, int CinP, int CoutP, WgradTileArgs* a);
 void dsr_launch_wgrad_taps(const WgradTileArgs& a, int KH, int ychunks, int dtype, hipStream_t st);
 

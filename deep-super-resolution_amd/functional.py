@@ -536,6 +536,12 @@ class ConvAct(torch.autograd.Function):
         # (defer: nothing is launched here -- the layer that consumes y computes this layer inside its own forward kernel and
         #  fills y only if a backward pass will need it: ConvBNAct with cfg["first2"], the discriminator's first two layers)
         ctx.desc, ctx.cfg, ctx.ps, ctx.act = desc, cfg, ps, act
+        opl = cfg.get("out_ps_link")
+        if opl is not None:
+            # the 9x9 tail that consumes y may run this layer's activation backward inside its input-gradient launch
+            opl.clear()
+            if ps and act == ACT_PRELU and prelu is not None and cout == 256:
+                opl["prelu"] = prelu.detach()
         ctx.wshape = tuple(weight.shape)
         ctx.weight_ref = weight
         ctx.weight_version = _version(weight)
@@ -556,7 +562,12 @@ class ConvAct(torch.autograd.Function):
             # gradient kernel (dsr_conv_dgrad_first_bwd) and left the results here; `dout` is a placeholder without storage
             dw, db = link.pop("grads")
             return None, dw, db, None, None
-        dout = dout.contiguous()
+        opl = ctx.cfg.get("out_ps_link")
+        got = opl.pop("dy", None) if opl is not None else None
+        if opl is not None:
+            opl.clear()
+        if got is None:
+            dout = dout.contiguous()     # (otherwise a placeholder without storage: see below)
         cout = desc.Cout
         n = x.shape[0]
         oh, ow = _out_hw(desc)
@@ -585,7 +596,19 @@ class ConvAct(torch.autograd.Function):
                     _ptr(ws), wsz, _stream()), name="conv_first_bwd_kernel"))
             return None, dw, db, None, None
         out_link = ctx.cfg.get("out_link")
-        if (out_link is not None and out_link.premasked and prelu is None and not ctx.ps
+        if got is not None:
+            # the tail's input-gradient launch (dsr_conv_dgrad_ps) already produced the masked, un-shuffled gradient of this
+            # layer's conv output and the partial sums; `dout` is a placeholder without storage
+            dy, part, blocks = got
+            db = dprelu = None
+            if ctx.has_bias:
+                db = torch.empty(cout, dtype=torch.float32, device=x.device)
+                check(lib.dsr_pw_sum_rows(_ptr(part), blocks, 2 * cyp, 0, cout, 1.0, _ptr(db), 0, 1, _stream()))
+            chan = torch.empty(cyp, dtype=torch.float32, device=x.device)
+            check(lib.dsr_pw_sum_rows(_ptr(part), blocks, 2 * cyp, cyp, cyp, 1.0, _ptr(chan), 0, 1, _stream()))
+            dprelu = torch.empty(1, dtype=torch.float32, device=x.device)
+            check(lib.dsr_pw_sum_rows(_ptr(chan), cyp, 1, 0, 1, 1.0, _ptr(dprelu), 0, 0, _stream()))
+        elif (out_link is not None and out_link.premasked and prelu is None and not ctx.ps
                 and not (ctx.has_bias and ctx.needs_input_grad[2])):
             # the consumer of this layer's output already multiplied dout by act'(y) (ActLink): nothing left to do here
             out_link.premasked = False
@@ -619,6 +642,7 @@ class ConvAct(torch.autograd.Function):
 
 FIRST2_BACKWARD = os.environ.get("DSR_FIRST2_BACKWARD", "1") != "0"   # 0: the first two layers' backward as separate launches
 DGRAD_BN = os.environ.get("DSR_DGRAD_BN_LINK", "1") != "0"             # 0: BatchNorm-backward sums always by their own reduce pass
+DGRAD_PS = os.environ.get("DSR_DGRAD_PS_LINK", "1") != "0"             # 0: the PixelShuffle-PReLU backward always as its own pass
 
 
 def _first2_backward(ctx, desc, x, dy, wd):
@@ -847,6 +871,7 @@ class ConvOutNCHW(torch.autograd.Function):
         check(_timed("fwd", desc, lambda: _lib.lib().dsr_conv_fwd(C.byref(desc), _ptr(x), _ptr(wf), C.byref(ep), None,
                                                                     _stream()), ep))
         ctx.desc, ctx.act = desc, act
+        ctx.ps_link = cfg.get("in_ps_link")
         ctx.wshape = tuple(weight.shape)
         ctx.weight_ref = weight
         ctx.has_bias = bias is not None
@@ -862,8 +887,26 @@ class ConvOutNCHW(torch.autograd.Function):
         dy = torch.empty((n, h, w, r8(c)), dtype=x.dtype, device=x.device)
         check(_lib.lib().dsr_pw_act_bwd_nchw(_dt(x), _ptr(dout), _ptr(out), _ptr(dy), n, c, h, w, r8(c), ctx.act,
                                              _stream()))
-        dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape,
-                                 getattr(ctx, "weight_ref", None))
+        lib = _lib.lib()
+        link = getattr(ctx, "ps_link", None)
+        if (link is not None and "prelu" in link and DGRAD_PS and ctx.needs_input_grad[0]
+                and lib.dsr_conv_dgrad_ps_supported(C.byref(desc))):
+            # x is PReLU(PixelShuffle(conv)) (generator.py:37-39 in front of :78): that activation's backward rides in this
+            # layer's input-gradient launch (dsr_conv_dgrad_ps) -- the 64-channel gradient at the high resolution is never
+            # written; the shuffle conv's node finds the un-shuffled, masked gradient and the partial sums in the link
+            n_, h_, w_, _ = x.shape
+            rows = lib.dsr_conv_dgrad_ps_rows(C.byref(desc))
+            dyu = torch.empty((n_, h_ // 2, w_ // 2, 256), dtype=x.dtype, device=x.device)
+            part = torch.empty((rows + _scr()) * 2 * 256, dtype=torch.float32, device=x.device)
+            check(_timed("dgrad", desc, lambda: lib.dsr_conv_dgrad_ps(C.byref(desc), _ptr(dy), _ptr(wd), _ptr(x), _ptr(link["prelu"]),
+                                                                       _ptr(dyu), _ptr(part), _stream()),
+                         name="conv_dgrad_toeplitz9_kernel<ps>"))
+            link["dy"] = (dyu, part, rows)
+            dx = torch.empty(1, dtype=x.dtype, device=x.device).expand(x.shape)       # placeholder without storage
+            _, dw = _conv_backward(desc, x, dy, wd, False, ctx.needs_input_grad[1], ctx.wshape, getattr(ctx, "weight_ref", None))
+        else:
+            dx, dw = _conv_backward(desc, x, dy, wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wshape,
+                                     getattr(ctx, "weight_ref", None))
         db = _colsum(dy, c) if ctx.has_bias else None
         return dx, dw, db, None
 

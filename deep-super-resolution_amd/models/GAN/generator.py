@@ -60,8 +60,10 @@ class PixelShuffleBlock(nn.Module):
         self.prelu1 = nn.PReLU()
         self.compute_dtype = torch.bfloat16
 
-    def _block(self, x):
+    def _block(self, x, out_ps_link=None):
         cfg = dict(stride=1, pad=1, act=F.ACT_PRELU, pixel_shuffle=True)
+        if out_ps_link is not None:
+            cfg["out_ps_link"] = out_ps_link
         return F.ConvAct.apply(x, self.conv1.weight, self.conv1.bias, self.prelu1.weight, cfg)   # :37-39 fused
 
     def forward(self, x):
@@ -107,7 +109,11 @@ class Generator(nn.Module):
                               self.bn1.running_mean, self.bn1.running_var, self.bn1.num_batches_tracked,
                               None, x0, dict(stride=1, pad=1, act=F.ACT_NONE, train=self.training,
                                        bn_updates=self.bn_updates))                                   # :71-74
-        for block in self.pixel_shuffle_blocks:                                                   # :76
-            z = block._block(z)
+        # (`psl`: the 9x9 tail's input-gradient launch also runs the backward of the last PixelShuffle + PReLU, dsr_conv_dgrad_ps:
+        #  that block leaves its PReLU weight in the link and finds the masked, un-shuffled gradient of its conv output there)
+        psl = {}
+        nps = len(self.pixel_shuffle_blocks)
+        for i, block in enumerate(self.pixel_shuffle_blocks):                                     # :76
+            z = block._block(z, psl if i + 1 == nps else None)
         return F.ConvOutNCHW.apply(z, self.conv3.weight, self.conv3.bias,
-                                   dict(stride=1, pad=4, act=F.ACT_TANH))                       # :78-80
+                                   dict(stride=1, pad=4, act=F.ACT_TANH, in_ps_link=psl))       # :78-80

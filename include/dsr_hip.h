@@ -107,6 +107,17 @@ int dsr_conv_first_bwd(const dsr_conv_desc* d, const void* x, const void* dout, 
 int dsr_conv_first_bwd_recompute(const dsr_conv_desc* d, const void* x, const void* dout, const float* w, const float* bias,
                                  int act, float slope, float* dw, float* db, void* workspace, size_t ws_bytes, dsr_stream_t s);
 
+/* dsr_conv_dgrad of the 9x9 64 -> 3 tail (generator.py:78) whose input is PReLU(PixelShuffle(2)(conv)) (generator.py:37-39), with
+ * that activation's whole backward in the same launch: the gradient w.r.t. the tail's input is never written; what comes out is
+ * dyu [N][H/2][W/2][256], the gradient of the shuffle conv's output (channel 4c + 2i + j <- pixel (2h+i, 2w+j), masked by the
+ * PReLU derivative taken from the sign of act_out = the tail's own input), and dsr_conv_dgrad_ps_rows(d) partial rows of [2][256]:
+ * the column sums of dyu (that conv's bias gradient) and the PReLU-weight gradient terms (column 0 of the second slice) --
+ * exactly what dsr_pw_act_bwd(pixshuf = 1) produces from dx and act_out.  prelu: the (positive) PReLU weight on the device. */
+int dsr_conv_dgrad_ps_supported(const dsr_conv_desc* d);
+int dsr_conv_dgrad_ps_rows(const dsr_conv_desc* d);
+int dsr_conv_dgrad_ps(const dsr_conv_desc* d, const void* dy, const void* w_dgrad, const void* act_out, const float* prelu,
+                      void* dyu, float* partial, dsr_stream_t s);
+
 /* dsr_conv_dgrad of a 3x3 stride-2 layer (discriminator.py:31,33,35) whose input is the output of BatchNorm + LeakyReLU
  * (:14-19), with the two per-channel sums the BatchNorm backward of that layer needs formed in the same launch: partial gets
  * dsr_conv_dgrad_bn_rows(d) rows of [3][r8(Cin)] = (sum g, sum g*y, 0) with g = dx * act'(scale*y + shift) -- what

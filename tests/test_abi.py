@@ -89,6 +89,7 @@ def test_bad_arguments_return_codes_not_crashes(so):
         lambda: lib.dsr_conv_first_bwd_recompute(ctypes.byref(d), N, N, N, N, 1, 0.2, N, N, N, 0, st),
         lambda: lib.dsr_conv_dgrad_first_bwd(ctypes.byref(d), ctypes.byref(d), N, N, N, N, N, 1, 0.2, N, N, N, 0, st),   # not a layer pair
         lambda: lib.dsr_conv_dgrad_bn(ctypes.byref(d), N, N, N, N, N, N, 1, 0.2, N, st),          # stride 1
+        lambda: lib.dsr_conv_dgrad_ps(ctypes.byref(d), N, N, N, N, N, N, st),                        # not the 9x9 tail
         lambda: lib.dsr_pw_nchw_to_nhwc(0, N, N, 1, 3, 4, 4, 8, st),
         lambda: lib.dsr_pw_nhwc_to_nchw(0, one, one, 1, 3, 4, 4, 7, st),          # Cp % 8
         lambda: lib.dsr_pw_sum_rows(N, 4, 8, 0, 8, 1.0, N, 0, 1, st),

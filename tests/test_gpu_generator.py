@@ -293,3 +293,56 @@ def test_residual_skip_gradient_fused_equals_autograd_sum(dev):
     (o_a, gx_a, gp_a), (o_b, gx_b, gp_b) = res
     assert torch.equal(o_a, o_b) and torch.equal(gx_a, gx_b)
     assert len(gp_a) == len(gp_b) and all(torch.equal(a, b) for a, b in zip(gp_a, gp_b))
+
+
+@pytest.mark.parametrize("factor,hw", [(4, (20, 24)), (2, (16, 16))])
+def test_tail_backward_with_the_pixel_shuffle_prelu_backward_inside(dev, factor, hw, monkeypatch):
+    """Generator.forward links its last PixelShuffleBlock to the 9x9 tail: the tail's input-gradient launch (dsr_conv_dgrad_ps)
+    then also runs that block's PixelShuffle + PReLU backward -- mask, un-shuffle, bias-gradient sums, PReLU-weight gradient --
+    and the 64-channel gradient at the output resolution is never written; functional.DGRAD_PS off runs the separate pass.  Same
+    module, weights and batch: identical output, the launch taken exactly when expected, every parameter gradient and the
+    input gradient equal to the rounding of that one tensor (rounded once instead of twice) -- cosine and norm, as everywhere
+    in this file -- and the fused gradients no further from the oracle's than the unfused ones."""
+    F = P("functional")
+    x = filler.tensor("in:tailps", (2, 3) + hw, 0.5, 0.5)
+    probe = filler.tensor("probe:tailps", (2, 3, hw[0] * factor, hw[1] * factor))
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(F, "DGRAD_PS", on)
+        g, sd = build(dev, factor, 2)
+        g.train()
+        xg = x.to(dev).requires_grad_(True)
+        F.KERNEL_LOG = []
+        try:
+            y = g(xg)
+            (y * probe.to(dev)).sum().backward()
+            torch.cuda.synchronize()
+            names = [e[4] for e in F.KERNEL_LOG]
+        finally:
+            F.KERNEL_LOG = None
+        assert any("kernel<ps>" in nm for nm in names) == on, names
+        res[on] = (y.detach().clone(), {k: p.grad.clone() for k, p in g.named_parameters() if p.grad is not None}, xg.grad.clone())
+    (ya, ga, dxa), (yb, gb, dxb) = res[True], res[False]
+    assert torch.equal(ya, yb) and set(ga) == set(gb)
+    for k in ga:
+        assert torch.isfinite(ga[k]).all(), k
+        if ga[k].numel() == 1:
+            continue      # (a PReLU weight's gradient is a sum over a whole tensor with cancellation: judged against the oracle below)
+        assert cos(ga[k], gb[k]) > 0.999 and abs(float(ga[k].norm() / gb[k].norm().clamp_min(1e-30)) - 1) < 2e-2, (k, cos(ga[k], gb[k]))
+    assert cos(dxa, dxb) > 0.999
+    # conv3 (the tail) itself is untouched by the fusion: bit-identical
+    assert torch.equal(ga["conv3.weight"], gb["conv3.weight"]) and torch.equal(ga["conv3.bias"], gb["conv3.bias"])
+    # against the oracle
+    osd = {k: v.clone() for k, v in sd.items()}
+    recipes.leaves(osd)
+    yr = gan.generator_forward(osd, x, True)
+    (yr * probe).sum().backward()
+    last = f"pixel_shuffle_blocks.{int(np.log2(factor)) - 1}"
+    for k in (last + ".conv1.weight", last + ".conv1.bias"):
+        cf, cu = cos(ga[k].cpu(), osd[k].grad), cos(gb[k].cpu(), osd[k].grad)
+        assert cf > 0.98 and cf > cu - 5e-3, (k, cf, cu)
+    for k in ga:
+        if ga[k].numel() == 1:      # the one-element gradients: the fused path no further from the oracle than the unfused one (+ 5 %)
+            ref = float(osd[k].grad)
+            ef, eu = abs(float(ga[k]) - ref) / abs(ref), abs(float(gb[k]) - ref) / abs(ref)
+            assert ef < max(0.15, 1.5 * eu), (k, float(ga[k]), float(gb[k]), ref)

@@ -482,6 +482,68 @@ def test_first_layer_fused_backward(dev, n, h, w, actn):
     assert rel_err(dw_f, dw_u) < 5e-3 and rel_err(db_f, db_u) < 5e-3
 
 
+@pytest.mark.parametrize("n,h,w,slope", [(2, 32, 48, 0.25), (1, 70, 130, 0.1), (3, 16, 16, 0.25), (1, 256, 64, 0.3)])
+def test_tail_input_gradient_with_pixel_shuffle_prelu_backward(dev, n, h, w, slope):
+    """dsr_conv_dgrad_ps -- the input gradient of the 9x9 64 -> 3 tail (generator.py:78) with the backward of the
+    PixelShuffle(2) + PReLU in front of it (generator.py:37-39) in its epilogue: masked, UN-shuffled gradient of the shuffle
+    conv's output, its column sums (bias gradient) and the PReLU-weight gradient, without ever writing the 64-channel gradient
+    at the high resolution -- against the two launches it replaces (dsr_conv_dgrad, then dsr_pw_act_bwd with pixshuf = 1, which
+    sees the gradient rounded to bf16 first) and against float64 PyTorch on the same bf16 operands.  Strips with ragged right
+    edges (width 48, 130), several row bands per strip (height 256), an odd number of rows per band before rounding."""
+    import ctypes as C
+    L = P("_lib")
+    F = P("functional")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cpu").manual_seed(h + w)
+    dy3 = bfr(torch.rand(n, 3, h, w, generator=g) - 0.5)
+    wt = bfr((torch.rand(3, 64, 9, 9, generator=g) - 0.5) * 0.05)
+    out = bfr(torch.randn(n, 64, h, w, generator=g))             # the activation output: sign = PReLU branch
+    d = L.ConvDesc(L.BF16, n, h, w, 64, 3, 9, 9, 1, 4, 0)
+    assert lib.dsr_conv_dgrad_ps_supported(C.byref(d)) == 1
+    wf = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 0), dtype=torch.bfloat16, device=dev)
+    wd = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 1), dtype=torch.bfloat16, device=dev)
+    L.check(lib.dsr_conv_pack_weight(C.byref(d), wt.to(dev).data_ptr(), wf.data_ptr(), wd.data_ptr(), st))
+    dyg, outg = to_nhwc(dy3).to(dev), to_nhwc(out, 64).to(dev)
+    prelu = torch.full((1,), slope, device=dev)
+    scr = lib.dsr_pw_scratch_rows()
+    lh, lw = h // 2, w // 2
+    # ---- one launch
+    rows = lib.dsr_conv_dgrad_ps_rows(C.byref(d))
+    part_f = torch.full(((rows + scr) * 2 * 256,), float("nan"), dtype=torch.float32, device=dev)
+    dyu_f = torch.full((n, lh, lw, 256), float("nan"), dtype=torch.bfloat16, device=dev)
+    L.check(lib.dsr_conv_dgrad_ps(C.byref(d), dyg.data_ptr(), wd.data_ptr(), outg.data_ptr(), prelu.data_ptr(), dyu_f.data_ptr(),
+                                  part_f.data_ptr(), st))
+    # ---- two launches
+    dx = torch.empty((n, h, w, 64), dtype=torch.bfloat16, device=dev)
+    wsz = lib.dsr_conv_dgrad_workspace(C.byref(d))
+    ws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=dev)
+    L.check(lib.dsr_conv_dgrad(C.byref(d), dyg.data_ptr(), wd.data_ptr(), dx.data_ptr(), ws.data_ptr(), wsz, st))
+    p = n * lh * lw
+    blocks, rpb = F._reduce_blocks(p)
+    part_t = torch.empty((blocks + scr) * 2 * 256, dtype=torch.float32, device=dev)
+    dyu_t = torch.empty((n, lh, lw, 256), dtype=torch.bfloat16, device=dev)
+    L.check(lib.dsr_pw_act_bwd(L.BF16, dx.data_ptr(), outg.data_ptr(), dyu_t.data_ptr(), n, lh, lw, 256, 64, 1, F.ACT_PRELU, 0.0,
+                               prelu.data_ptr(), blocks, rpb, part_t.data_ptr(), st))
+    torch.cuda.synchronize()
+    # ---- float64 reference: d = conv_transpose (= dgrad), g = d * PReLU'(out), un-shuffle, sums
+    dref = TF.conv_transpose2d(dy3.double(), wt.double(), padding=4)                      # [n, 64, h, w]
+    od = out.double()
+    gref = torch.where(od >= 0, dref, dref * slope)
+    dyu_ref = TF.pixel_unshuffle(gref, 2)                                                  # channel 4c + 2i + j
+    db_ref = dyu_ref.sum(dim=(0, 2, 3))
+    dp_ref = float((dref * (od / slope) * (od < 0)).sum())
+    got_f, got_t = from_nhwc(dyu_f.cpu(), 256).double(), from_nhwc(dyu_t.cpu(), 256).double()
+    assert torch.isfinite(got_f).all()
+    scale = float(dyu_ref.abs().max())
+    assert float((got_f - dyu_ref).abs().max()) < 6e-3 * scale                            # one bf16 rounding of g
+    assert float((got_t - dyu_ref).abs().max()) < 1.2e-2 * scale                          # two (d, then g)
+    for part, nb, tol in ((part_f, rows, 2e-3), (part_t, blocks, 4e-3)):
+        pr = part[:nb * 2 * 256].view(nb, 2, 256).cpu().double().sum(0)
+        assert float((pr[0] - db_ref).abs().max()) < tol * float(dyu_ref.abs().sum(dim=(0, 2, 3)).max())
+        assert abs(float(pr[1].sum()) - dp_ref) < tol * float((dref * (od / slope) * (od < 0)).abs().sum())
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout,actn", [(2, 32, 32, 128, 128, "leaky"), (3, 64, 64, 256, 256, "leaky"), (1, 4, 512, 64, 128, "none"),
                                                   (40, 64, 64, 128, 64, "leaky"), (2, 32, 32, 512, 512, "leaky")])
 def test_conv_dgrad_with_batchnorm_backward_sums(dev, n, h, w, cin, cout, actn):
