@@ -874,6 +874,9 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_toeplitz9_kernel(const Tail
       f32x4 acc[4];
 #pragma unroll
       for (int mf = 0; mf < 4; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // (PS: as in conv_c64_kernel, everything outside the MFMA phase runs at priority 1 -- the other block's MFMA stream otherwise
+      //  gets two issue slots for every one of this wave's mask / un-shuffle instructions)
+      if constexpr (PS) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int kh = 0; kh < 9; ++kh) {
         const int y = r - kh + 4;
@@ -883,6 +886,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_toeplitz9_kernel(const Tail
           for (int mf = 0; mf < 4; ++mf) acc[mf] = mfma16<DT>(fw[kh][mf], fb, acc[mf]);
         }
       }
+      if constexpr (PS) __builtin_amdgcn_s_setprio(1);
       if constexpr (PS) {
         // acc[mf][j] = d(channel 16 mf + 4 g + j, pixel l16): g = d * PReLU'(o), PReLU-weight terms d * o / slope where o < 0
         const unsigned char* so = sO + (r & 1) * O_STRIP + px * 128 + (g & 1) * 8;
