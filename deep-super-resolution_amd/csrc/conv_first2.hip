@@ -18,6 +18,8 @@
 #include <stdlib.h>
 
 #include "../../include/dsr_hip.h"
+#include <type_traits>
+
 #include "dsr_common.h"
 #include "dsr_kernels.h"
 
@@ -37,6 +39,33 @@ constexpr int F2_LDS = F2_OFF_STAT + 8 * 2 * 32 * 4;        // 122,112 B
 constexpr int F2_GROUPS = F2_AR * 4 + 1;                    // stage-1 pixel groups: 4 x 16 columns per a0 row + the 65th column of all rows
 static_assert(F2_TR * F2_TC * F2_CSTRIDE <= F2_A, "the C tile is staged over the a0 halo");
 }   // namespace
+
+// one v_max_f32 (fmaxf adds a canonicalising v_max(x, x) per operand)
+__device__ __forceinline__ float f2_vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// sum over the 16 lanes of a DPP row; every lane ends up with it
+__device__ __forceinline__ float row16_sum(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1, 0, 3, 2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2, 3, 0, 1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror
+  return v;
+}
+
+#ifdef DSR_F2_STAMPS
+// Diagnostic build only (tools/diag_first2.cpp): per-block cycle sums of the phases of a tile, stamped by s_memtime on wave 0; the
+// values go to a buffer nothing else reads.
+__device__ unsigned long long f2_stamps[256][12];
+#define F2_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); f2_acc[k] += now_ - f2_last; f2_last = now_; } while (0)
+#else
+#define F2_STAMP(k)
+#endif
 
 template <int DT>
 __global__ __launch_bounds__(512, 2) void conv_first2_kernel(const First2Args a) {
@@ -137,13 +166,21 @@ __global__ __launch_bounds__(512, 2) void conv_first2_kernel(const First2Args a)
   fetch(cur, 0);
   int buf = 0;
   float stat_acc = 0.f;
+#ifdef DSR_F2_STAMPS
+  unsigned long long f2_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long f2_begin = __builtin_amdgcn_s_memtime();
+  unsigned long long f2_last = f2_begin;
+#endif
   for (; t < a.ntiles; t += tstep, buf ^= 1) {
     const bool has_next = t + tstep < a.ntiles;
     const TileXY nxt = has_next ? decomp(t + tstep) : cur;
     // this tile's image halo has landed (first tile: and sW0 / sB0 are written); everyone is done with the previous tile
+    F2_STAMP(8);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    F2_STAMP(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    F2_STAMP(1);
     if (has_next) fetch(nxt, buf ^ 1);
     const int ay0 = 2 * cur.ty * F2_TR - 1, ax0 = 2 * cur.tx * F2_TC - 1;   // a0 coordinates of halo slot (0, 0)
     // ================================================================ stage 1: a0 halo -> LDS
@@ -152,12 +189,18 @@ __global__ __launch_bounds__(512, 2) void conv_first2_kernel(const First2Args a)
       int l1 = lane;
       asm volatile("" : "+v"(l1));
       const int gg = l1 >> 4, rr = l1 & 15;
+      const bool interior = ay0 >= 0 && ay0 + F2_AR <= a.H && ax0 >= 0 && ax0 + F2_AC <= a.W;     // (uniform)
+      const bool small_slope = a.slope0 <= 1.f;
       int toff[3];                                           // byte offset of this lane's tap in k-step ks (taps >= 9: weights are zero)
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
         const int tap = 4 * ks + gg;
         toff[ks] = tap < 9 ? ((tap / 3) * F2_XC + tap % 3) * 16 : 0;
       }
+      // (one instantiation per (interior tile, slope <= 1): the common one has neither the per-element border select nor the
+      //  compare + select form of LeakyReLU; chosen by a wave-uniform branch)
+      auto stage1 = [&](auto interior_c, auto small_c) {
+        constexpr bool INTERIOR = decltype(interior_c)::value, SMALL = decltype(small_c)::value;
       for (int j = wave; j < F2_GROUPS; j += 8) {
         int ar, ac;
         bool lane_ok = true;
@@ -174,7 +217,8 @@ __global__ __launch_bounds__(512, 2) void conv_first2_kernel(const First2Args a)
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) fb[ks] = *reinterpret_cast<const U4*>(px + toff[ks]);
         const int ay = ay0 + ar, ax = ax0 + ac;
-        const bool inside = lane_ok && (unsigned)ay < (unsigned)a.H && (unsigned)ax < (unsigned)a.W;
+        // (tiles whose whole halo lies inside the image -- all but the border ones -- skip the per-element select; uniform)
+        [[maybe_unused]] const bool inside = lane_ok && (unsigned)ay < (unsigned)a.H && (unsigned)ax < (unsigned)a.W;
         const int slot = ar * F2_AP + (ac & 1) * 40 + (ac >> 1);
         f32x4 acc4[4];
 #pragma unroll
@@ -189,8 +233,13 @@ __global__ __launch_bounds__(512, 2) void conv_first2_kernel(const First2Args a)
           float v[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float o = acc[q] >= 0.f ? acc[q] : acc[q] * a.slope0;
-            v[q] = inside ? o : 0.f;
+            // LeakyReLU: max(x, x * slope) for 0 <= slope <= 1 (one instruction less than compare + select)
+            float o;
+            if constexpr (SMALL)
+              o = f2_vmax(acc[q], acc[q] * a.slope0);
+            else
+              o = acc[q] >= 0.f ? acc[q] : acc[q] * a.slope0;
+            v[q] = INTERIOR ? o : (inside ? o : 0.f);
           }
           uint2 h;
           h.x = (unsigned)f2h<DT>(v[0]) | ((unsigned)f2h<DT>(v[1]) << 16);
@@ -198,10 +247,19 @@ __global__ __launch_bounds__(512, 2) void conv_first2_kernel(const First2Args a)
           if (lane_ok) *reinterpret_cast<uint2*>(sA + slot * 128 + (((2 * nt + (gg >> 1)) ^ (slot & 7)) << 4) + (gg & 1) * 8) = h;
         }
       }
+      };
+      if (interior && small_slope)
+        stage1(std::true_type{}, std::true_type{});
+      else if (small_slope)
+        stage1(std::false_type{}, std::true_type{});
+      else
+        stage1(std::false_type{}, std::false_type{});
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    F2_STAMP(2);
     __builtin_amdgcn_s_barrier();                            // the a0 halo is complete
     asm volatile("" ::: "memory");
+    F2_STAMP(3);
     // ---- a0 to HBM (training): the tile's own 8 x 64 pixels (halo slots (1..8, 1..64)), full 128-byte lines
     if (a.a0) {
       int tv = tid;
@@ -219,6 +277,7 @@ __global__ __launch_bounds__(512, 2) void conv_first2_kernel(const First2Args a)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), arsrc, off, 0, 0);
       }
     }
+    F2_STAMP(4);
     // ================================================================ stage 2: 3x3 stride 2 from the LDS halo
     f32x4 acc[2][2];
 #pragma unroll
@@ -245,8 +304,10 @@ __global__ __launch_bounds__(512, 2) void conv_first2_kernel(const First2Args a)
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    F2_STAMP(5);
     __builtin_amdgcn_s_barrier();                            // every wave is done reading the a0 halo: it becomes the C tile
     asm volatile("" ::: "memory");
+    F2_STAMP(6);
     // ================================================================ epilogue
     const int oy0 = cur.ty * F2_TR, ox0 = cur.tx * F2_TC;
     unsigned char* sC = sA;
@@ -280,11 +341,11 @@ __global__ __launch_bounds__(512, 2) void conv_first2_kernel(const First2Args a)
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int x = 1; x < 16; x <<= 1) {                // over the 16 pixels (lanes r16) of the fragment
-              s1[nt][j] += __shfl_xor(s1[nt][j], x, 64);
-              s2[nt][j] += __shfl_xor(s2[nt][j], x, 64);
-            }
+            // over the 16 pixels (lanes r16) of the fragment: four DPP adds (lane ^ 1, lane ^ 2 inside a quad, then the mirrored
+            // quad pair and the mirrored half row -- every lane of a quad holds the quad's sum by then) instead of four
+            // ds_bpermute round trips
+            s1[nt][j] = row16_sum(s1[nt][j]);
+            s2[nt][j] = row16_sum(s2[nt][j]);
           }
         if (r16 == 0) {
 #pragma unroll
@@ -298,8 +359,10 @@ __global__ __launch_bounds__(512, 2) void conv_first2_kernel(const First2Args a)
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    F2_STAMP(7);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    F2_STAMP(6);
     if (a.stats && tid < 128) {
       // channel c = tid & 63 lives in half c >> 5, i.e. waves 4 (c >> 5) + 0..3 (the tile's four rows), fixed order
       const int which = tid >> 6, c = tid & 63, hb = (c >> 5) * 4, ci = c & 31;
@@ -323,7 +386,17 @@ __global__ __launch_bounds__(512, 2) void conv_first2_kernel(const First2Args a)
       }
     }
     cur = nxt;
+    F2_STAMP(9);
+#ifdef DSR_F2_STAMPS
+    f2_acc[10] += 1;
+#endif
   }
+#ifdef DSR_F2_STAMPS
+  if (tid == 0) {
+    f2_acc[11] = __builtin_amdgcn_s_memtime() - f2_begin;
+    for (int i = 0; i < 12; ++i) f2_stamps[blockIdx.x][i] = f2_acc[i];
+  }
+#endif
   if (a.stats && tid < 128) a.stats[((size_t)blockIdx.x * 2 + (tid >> 6)) * 64 + (tid & 63)] = stat_acc;
 }
 
