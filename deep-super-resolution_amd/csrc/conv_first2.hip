@@ -46,18 +46,6 @@ __device__ __forceinline__ float f2_vmax(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-// sum over the 16 lanes of a DPP row; every lane ends up with it
-__device__ __forceinline__ float row16_sum(float v) {
-  auto dpp = [](float x, auto ctrl) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
-  };
-  v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1, 0, 3, 2]
-  v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2, 3, 0, 1]
-  v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
-  v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror
-  return v;
-}
-
 #ifdef DSR_F2_STAMPS
 // Diagnostic build only (tools/diag_first2.cpp): per-block cycle sums of the phases of a tile, stamped by s_memtime on wave 0; the
 // values go to a buffer nothing else reads.

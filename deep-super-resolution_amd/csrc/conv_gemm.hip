@@ -523,11 +523,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 224 * 25
         if constexpr (ST) {
   #pragma unroll
           for (int j = 0; j < 4; ++j) {
-  #pragma unroll
-            for (int x = 1; x < 16; x <<= 1) {          // over the 16 pixels (lanes r16) of the fragment
-              s1[j] += __shfl_xor(s1[j], x, 64);
-              s2[j] += __shfl_xor(s2[j], x, 64);
-            }
+              s1[j] = row16_sum(s1[j]);          // over the 16 pixels (lanes r16) of the fragment: DPP, dsr_common.h
+            s2[j] = row16_sum(s2[j]);
           }
           if (r16 == 0) {
   #pragma unroll

@@ -212,6 +212,21 @@ __device__ __forceinline__ void lds_dma16(const BufSrd& srd, const void* lds, un
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(l), "v"(voff), "s"(srd.w) : "memory");
 }
 
+// Sum over the 16 lanes of a DPP row (the 16 pixels of an MFMA fragment); every lane ends up with it.  Four DPP adds -- lane ^ 1
+// and lane ^ 2 inside a quad, then the mirrored quad pair and the mirrored half row (every lane of a quad holds the quad's sum
+// by then) -- i.e. the summation tree of __shfl_xor(1, 2, 4, 8) without its four ds_bpermute round trips through the LDS.
+template <int CTRL>
+__device__ __forceinline__ float dsr_dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dsr_dpp_add<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+  v = dsr_dpp_add<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+  v = dsr_dpp_add<0x141>(v);      // row_half_mirror
+  v = dsr_dpp_add<0x140>(v);      // row_mirror
+  return v;
+}
+
 // XCD-aware, bijective block-id remap (consecutive logical tiles share an XCD's L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int nx = 8;
