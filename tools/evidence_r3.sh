@@ -16,6 +16,7 @@ timeout -k 10 100 python3 tools/microbench_dgrad_bn.py > $O/microbench_dgrad_bn.
 timeout -k 10 100 python3 tools/microbench_dgrad_ps.py > $O/microbench_dgrad_ps.txt 2>&1
 if [ -x tools/_bin/diag_dgrad_s2 ]; then
   { timeout -k 10 60 tools/_bin/diag_dgrad_s2 32 512 512 64 64 0; timeout -k 10 60 tools/_bin/diag_dgrad_s2 32 512 512 64 64 1; timeout -k 10 60 tools/_bin/diag_dgrad_s2 32 256 256 128 128 0; } > $O/diag_dgrad_s2.txt 2>&1
+  if [ -x tools/_bin/diag_first2 ]; then { timeout -k 10 60 tools/_bin/diag_first2 1; timeout -k 10 60 tools/_bin/diag_first2 0; } > $O/diag_first2.txt 2>&1; fi
 fi
 timeout -k 10 100 python3 tools/microbench_first_bwd.py > $O/microbench_first_bwd.txt 2>&1
 timeout -k 10 100 python3 tools/trace_step.py > $O/trace_step.txt 2>&1
