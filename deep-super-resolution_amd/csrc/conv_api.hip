@@ -176,6 +176,28 @@ extern "C" int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w
   if (fold && (!dsr_conv_fwd_affine_supported(d) || e->pixel_shuffle || e->out_nchw_f32 || e->stats_partial ||
                (!e->bn_scale) != (!e->bn_shift)))
     return dsr_fail(DSR_E_UNSUPPORTED, "conv_fwd: folded BatchNorm / residual epilogue not available for this layer");
+  if (!fold && !e->pixel_shuffle && !e->out_nchw_f32 && !e->stats_partial && r8(d->Cout) == 128 && d->Cout == 128 &&
+      (e->act == DSR_ACT_NONE || e->act == DSR_ACT_RELU || e->act == DSR_ACT_LEAKY) &&
+      dsr_halo64_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->H, d->W, r8(d->Cin), 128)) {
+    // 128 outputs over >= 128 input channels without BatchNorm statistics (VGG conv2_2, utils/GAN.py:26): two 64-channel
+    // slices per spatial tile on the halo-staged kernel (conv_halo64.hip) instead of the gather kernel's 128x128 tile
+    Halo64Args q;
+    memset(&q, 0, sizeof(q));
+    q.x = x;
+    q.w = w_fwd;
+    q.y = y;
+    q.bias = e->bias;
+    q.H = d->H;
+    q.W = d->W;
+    q.CinP = r8(d->Cin);
+    q.cout_full = 128;
+    q.mirror = 0;
+    q.act = e->act;
+    q.slope = e->slope;
+    q.flags = e->bias ? DSR_F_BIAS : 0;
+    dsr_launch_conv_halo64(q, d->N, d->dtype, s);
+    return dsr_launch_status("dsr_conv_fwd(halo64)");
+  }
   if (((is_c64(d) && !e->pixel_shuffle) || is_c64_wide(d)) && !e->out_nchw_f32) {
     C64Args c;
     memset(&c, 0, sizeof(c));
@@ -382,6 +404,7 @@ static int conv_dgrad_impl(const dsr_conv_desc* d, const void* dy, const void* w
     q.H = d->H;
     q.W = d->W;
     q.CinP = r8(d->Cout);
+    q.cout_full = r8(d->Cin);
     q.mirror = 1;
     q.act = DSR_ACT_NONE;
     q.mask_x = mask_x;
@@ -753,6 +776,10 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
     // (named like the symbols of a rocprof summary: <mode 0> statistics epilogue, <1> plain, <2> folded inference epilogue)
     if (((is_c64(d) && !ps) || is_c64_wide(d)) && !nchw)
       return (e && (e->bn_scale || e->residual)) ? "conv_c64_kernel<2>" : (stats ? "conv_c64_kernel<0>" : "conv_c64_kernel<1>");
+    if (!ps && !nchw && !stats && !(e && (e->bn_scale || e->residual)) && d->Cout == 128 &&
+        (!e || e->act == DSR_ACT_NONE || e->act == DSR_ACT_RELU || e->act == DSR_ACT_LEAKY) &&
+        dsr_halo64_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->H, d->W, r8(d->Cin), 128))
+      return "conv_halo64_kernel";
     if (is_cin8(d, e)) return "conv_cin8_kernel";
     if (d->Cout <= 16 && d->stride == 1 && d->pad_mode == DSR_PAD_ZERO && d->KH * d->KW >= 9 && !stats && !ps &&
         d->KW == 9 && d->KH <= 9 && r8(d->Cin) == 64)

@@ -1,4 +1,5 @@
-// 3x3 / stride 1 / zero-pad 1 convolution with 64 OUTPUT channels and a multiple of 32 input channels (128, 256): the input
+// 3x3 / stride 1 / zero-pad 1 convolution with 64 (or 128: two slices of 64, see `slices`) OUTPUT channels and a multiple of 32
+// input channels (128, 256): the input
 // gradients of the layers that widen 64 channels -- the PixelShuffle convs 64 -> 256 (models/GAN/generator.py:30: 620
 // GFLOP per batch-32 pass at 256x256), D's 64 -> 128 block (models/GAN/discriminator.py:31), VGG conv2_1 (utils/GAN.py:24).
 //
@@ -65,20 +66,25 @@ __global__ __launch_bounds__(512, 2) void conv_halo64_kernel(const Halo64Args a)
   int w_part[NWU];
 #pragma unroll
   for (int v = 0; v < NWU; ++v) {
-    const int row = 16 * (wave + 8 * v) + (lane >> 2);
-    w_part[v] = (row * a.CinP + (lane & 3) * 8) * 2;
+    const int row = 16 * (wave + 8 * v) + (lane >> 2);      // tap * 64 + channel of the slice
+    w_part[v] = (((row >> 6) * a.cout_full + (row & 63)) * a.CinP + (lane & 3) * 8) * 2;     // + slice * 64 * CinP * 2 per tile
   }
   const BufSrd wsrd = make_srd(a.w, a.w_bytes);
   const unsigned img_bytes = (unsigned)(a.H * a.W * a.CinP * 2);
   const int per_img = a.tiles_y * a.tiles_x;
 
+  const int slices = a.cout_full >> 6;                 // 64-channel output slices: tile t = (spatial tile, slice), slices of one
+                                                      // spatial tile on neighbouring blocks (the second read of its halo hits L2)
+  const int w_slice = 64 * a.CinP * 2, y_pix = a.cout_full * 2;
   struct TileXY {
-    int n, ty, tx;
+    int n, ty, tx, sl;
   };
   auto decomp = [&](int t) {
     TileXY c;
-    c.n = t / per_img;
-    const int rem = t - c.n * per_img;
+    const int ts = t / slices;
+    c.sl = t - ts * slices;
+    c.n = ts / per_img;
+    const int rem = ts - c.n * per_img;
     c.ty = rem / a.tiles_x;
     c.tx = rem - c.ty * a.tiles_x;
     return c;
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo64_kernel(const Halo64Args a)
 #pragma unroll
     for (int v = 0; v < NWU; ++v) {
       if (wave + 8 * v >= H64_WPIECES) continue;
-      lds_dma16(wsrd, wdst + (wave + 8 * v) * 1024, (unsigned)(w_part[v] + kb * 64));
+      lds_dma16(wsrd, wdst + (wave + 8 * v) * 1024, (unsigned)(w_part[v] + tc.sl * w_slice + kb * 64));
     }
   };
 
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo64_kernel(const Halo64Args a)
   const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.mask_x ? a.mask_x : a.y), 0, a.y_bytes, 0x00020000);
   const int cw_base = (16 * wq + r16) * H64_CSTRIDE + (32 * wc + 4 * g) * 2;      // + (row & 3) * 64 * CSTRIDE + nt * 32
   const int cr_base = (tid >> 3) * H64_CSTRIDE + (tid & 7) * 16;                   // + it * 64 * CSTRIDE: row `it` of the half
-  const int st_part = ((tid >> 3) & 63) * 128 + (tid & 7) * 16;                     // byte offset inside an output row of the tile
+  const int st_part = ((tid >> 3) & 63) * y_pix + (tid & 7) * 16;                   // byte offset inside an output row of the tile
 
   const int tstep = gridDim.x;
   int t = blockIdx.x;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo64_kernel(const Halo64Args a)
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.flags & DSR_F_BIAS) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) bv[r] = a.bias[32 * wc + 16 * nt + 4 * g + r];
+          for (int r = 0; r < 4; ++r) bv[r] = a.bias[cur.sl * 64 + 32 * wc + 16 * nt + 4 * g + r];
         }
         acc[i][nt] = f32x4{bv[0], bv[1], bv[2], bv[3]};
       }
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo64_kernel(const Halo64Args a)
     // targets the other stage.  Two halves of 4 rows x 64 pixels.
     unsigned char* sC = sHalo + (buf ^ 1) * H64_HALO;
     const int oy0 = cur.ty * H64_TR, ox0 = cur.tx * H64_TC;
-    const unsigned sorg = (unsigned)(((cur.n * a.H + oy0) * a.W + ox0) * 128);
+    const unsigned sorg = (unsigned)(((cur.n * a.H + oy0) * a.W + ox0) * y_pix + cur.sl * 128);
     const bool full = oy0 + H64_TR <= a.H && ox0 + H64_TC <= a.W;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo64_kernel(const Halo64Args a)
       for (int it = 0; it < 4; ++it) {
         const U4 v = *reinterpret_cast<const U4*>(sC + cr_base + it * 64 * H64_CSTRIDE);
         const int row = half * 4 + it;
-        unsigned off = sorg + (unsigned)(row * a.W * 128 + st_part);
+        unsigned off = sorg + (unsigned)(row * a.W * y_pix + st_part);
         if (!full && !(oy0 + row < a.H && ox0 + ((tid >> 3) & 63) < a.W)) off = OOB;
         if (a.mask_x) {       // (uniform) dsr_conv_dgrad_masked: the stored gradient is multiplied by act'(mask_x), the activation OUTPUT
                               // this gradient is taken with respect to (same shape as y) -- as conv_gemm.hip's masked stores
@@ -241,17 +247,21 @@ __global__ __launch_bounds__(512, 2) void conv_halo64_kernel(const Halo64Args a)
 bool dsr_halo64_supported(int KH, int KW, int stride, int pad, int pad_mode, int H, int W, int CinP, int CoutP) {
   const char* e = getenv("DSR_CONV_HALO64");         // 0 = these layers stay on the gather kernel (read per call: a test compares the two)
   const bool on = !(e && e[0] == '0');
-  return on && KH == 3 && KW == 3 && stride == 1 && pad == 1 && pad_mode == DSR_PAD_ZERO && CoutP == 64 && CinP % 32 == 0 &&
-         CinP >= 128 && CinP <= 1024 && H >= 8 && W >= 32 && (size_t)H * W * CinP * 2 < 0x7FFFFF00ull;
+  // (CoutP == 128: two 64-channel slices per spatial tile, DSR_CONV_HALO64=1 keeps those on the gather kernel)
+  const bool two = CoutP == 128 && !(e && e[0] == '1');
+  return on && KH == 3 && KW == 3 && stride == 1 && pad == 1 && pad_mode == DSR_PAD_ZERO && (CoutP == 64 || two) && CinP % 32 == 0 &&
+         CinP >= 128 && CinP <= 1024 && H >= 8 && W >= 32 && (size_t)H * W * CinP * 2 < 0x7FFFFF00ull &&
+         (size_t)H * W * CoutP * 2 < 0x7FFFFF00ull;
 }
 
 void dsr_launch_conv_halo64(Halo64Args& a, int N, int dtype, hipStream_t st) {
   a.kblocks = a.CinP / 32;
   a.tiles_y = (a.H + H64_TR - 1) / H64_TR;
   a.tiles_x = (a.W + H64_TC - 1) / H64_TC;
-  a.ntiles = N * a.tiles_y * a.tiles_x;
-  a.w_bytes = (unsigned)(9 * 64 * a.CinP * 2);
-  a.y_bytes = (unsigned)((size_t)N * a.H * a.W * 128);
+  if (a.cout_full < 64) a.cout_full = 64;
+  a.ntiles = N * a.tiles_y * a.tiles_x * (a.cout_full / 64);
+  a.w_bytes = (unsigned)(9 * a.cout_full * a.CinP * 2);
+  a.y_bytes = (unsigned)((size_t)N * a.H * a.W * a.cout_full * 2);
   const int blocks = a.ntiles < 256 ? a.ntiles : 256;         // persistent: one 8-wave block per CU (156 KB of LDS each)
   static LdsOptIn optin[4];
 #define H64_LAUNCH(I, DTV, MIRV)                                                                      \

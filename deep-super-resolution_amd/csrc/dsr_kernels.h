@@ -268,6 +268,7 @@ struct Halo64Args {
   const void* mask_x; // optional: y *= mask_act'(mask_x), mask_x an activation output of y's shape (dsr_conv_dgrad_masked)
   int mask_act;
   float mask_slope;
+  int cout_full;      // output channels of the layer: 64, or 128 = two slices of 64 (0 is taken as 64)
   int kblocks, tiles_y, tiles_x, ntiles;      // filled by the launcher
   unsigned w_bytes, y_bytes;
 };

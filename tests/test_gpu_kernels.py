@@ -973,6 +973,76 @@ def test_conv_halo64_dgrad_vs_gather_kernel_and_fp32(dev, n, h, w, cout):
     assert float((outs["1"].float() != outs["0"].float()).float().mean()) < 0.05          # (different summation order: a few last bits)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 40, 100, 128, 128), (1, 67, 130, 256, 128), (3, 16, 64, 128, 256), (36, 16, 64, 128, 128)])
+def test_conv_halo64_two_slices_of_64_outputs(dev, n, h, w, cin, cout):
+    """conv_halo64_kernel on a layer with 128 outputs (forward: VGG conv2_2, utils/GAN.py:26, with bias + ReLU in the epilogue)
+    or 128 inputs (input gradient, plain and with the ReLU mask of the activation in front folded into its stores): two
+    64-channel slices per spatial tile.  Against the gather kernel (DSR_CONV_HALO64=1 keeps 128-channel results there: the same
+    products in another order) and float64 conv2d / conv_transpose2d on the same bf16 operands.  Ragged tiles, K = 128 and 256,
+    more (tile, slice) pairs than persistent blocks."""
+    import ctypes as C
+    import os
+    L = P("_lib")
+    F = P("functional")
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = L.ConvDesc(L.BF16, n, h, w, cin, cout, 3, 3, 1, 1, 0)
+    g = torch.Generator(device="cpu").manual_seed(cin + cout + h)
+    wt = bfr((torch.rand(cout, cin, 3, 3, generator=g) - 0.5) * 0.1)
+    bias = (torch.rand(cout, generator=g) - 0.5) * 0.2
+    x = bfr(torch.rand(n, cin, h, w, generator=g) - 0.5)
+    dy = bfr(torch.rand(n, cout, h, w, generator=g) - 0.5)
+    wf = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 0), dtype=torch.bfloat16, device=dev)
+    wd = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 1), dtype=torch.bfloat16, device=dev)
+    L.check(lib.dsr_conv_pack_weight(C.byref(d), wt.to(dev).data_ptr(), wf.data_ptr(), wd.data_ptr(), st))
+    xg, dyg, bg = to_nhwc(x, cin).to(dev), to_nhwc(dy, cout).to(dev), bias.to(dev)
+    ep = L.Epilogue(L.ACT_RELU, 0.0, None, bg.data_ptr(), None, 0, None)
+    do_fwd, do_dgrad = cout == 128, cin == 128
+    outs = {}
+    old = os.environ.get("DSR_CONV_HALO64")
+    try:
+        for mode in ("2", "1"):
+            os.environ["DSR_CONV_HALO64"] = mode
+            res = {}
+            if do_fwd:
+                name = lib.dsr_conv_kernel_name(C.byref(d), 0, C.byref(ep)).decode()
+                assert ("halo64" in name) == (mode == "2"), (mode, name)
+                y = torch.full((n, h, w, cout), float("nan"), dtype=torch.bfloat16, device=dev)
+                L.check(lib.dsr_conv_fwd(C.byref(d), xg.data_ptr(), wf.data_ptr(), C.byref(ep), y.data_ptr(), st))
+                res["y"] = y
+            if do_dgrad:
+                name = lib.dsr_conv_kernel_name(C.byref(d), 1, None).decode()
+                assert ("halo64" in name) == (mode == "2"), (mode, name)
+                dx = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
+                L.check(lib.dsr_conv_dgrad(C.byref(d), dyg.data_ptr(), wd.data_ptr(), dx.data_ptr(), None, 0, st))
+                res["dx"] = dx
+                if lib.dsr_conv_dgrad_masked_supported(C.byref(d)):
+                    dxm = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
+                    L.check(lib.dsr_conv_dgrad_masked(C.byref(d), dyg.data_ptr(), wd.data_ptr(), xg.data_ptr(), L.ACT_RELU, 0.0,
+                                                      dxm.data_ptr(), st))
+                    res["dxm"] = dxm
+            outs[mode] = res
+    finally:
+        if old is None:
+            os.environ.pop("DSR_CONV_HALO64", None)
+        else:
+            os.environ["DSR_CONV_HALO64"] = old
+    torch.cuda.synchronize()
+    refs = {}
+    if do_fwd:
+        refs["y"] = TF.relu(TF.conv2d(x.double(), wt.double(), bias.double(), padding=1))
+    if do_dgrad:
+        refs["dx"] = TF.conv_transpose2d(dy.double(), wt.double(), padding=1)
+        refs["dxm"] = refs["dx"] * (x.double() > 0)
+    for key in outs["2"]:
+        a_, b_ = outs["2"][key].float().cpu(), outs["1"][key].float().cpu()
+        assert torch.isfinite(a_).all(), key
+        ck = cin if key != "y" else cout
+        for o in (a_, b_):
+            assert rel_err(from_nhwc(o, ck), refs[key]) <= 6e-3, key                        # one bf16 rounding of the output
+        assert rel_err(a_, b_) <= 2.0 ** -7 and float((a_ != b_).float().mean()) < 0.05, key  # (another summation order)
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 64, 96, 64, 64), (1, 50, 38, 128, 192), (3, 32, 32, 256, 64)])
 def test_conv_dgrad_s2_single_launch_equals_four_launches(dev, n, h, w, cin, cout):
     """conv_dgrad_s2_kernel (3x3 stride 2 pad 1 input gradient, all four output-parity classes from one staged dY tile;
