@@ -176,9 +176,9 @@ extern "C" int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w
   if (fold && (!dsr_conv_fwd_affine_supported(d) || e->pixel_shuffle || e->out_nchw_f32 || e->stats_partial ||
                (!e->bn_scale) != (!e->bn_shift)))
     return dsr_fail(DSR_E_UNSUPPORTED, "conv_fwd: folded BatchNorm / residual epilogue not available for this layer");
-  if (!fold && !e->pixel_shuffle && !e->out_nchw_f32 && !e->stats_partial && r8(d->Cout) == 128 && d->Cout == 128 &&
+  if (!fold && !e->pixel_shuffle && !e->out_nchw_f32 && !e->stats_partial && d->Cout % 64 == 0 && d->Cout >= 128 &&
       (e->act == DSR_ACT_NONE || e->act == DSR_ACT_RELU || e->act == DSR_ACT_LEAKY) &&
-      dsr_halo64_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->H, d->W, r8(d->Cin), 128)) {
+      dsr_halo64_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->H, d->W, r8(d->Cin), d->Cout)) {
     // 128 outputs over >= 128 input channels without BatchNorm statistics (VGG conv2_2, utils/GAN.py:26): two 64-channel
     // slices per spatial tile on the halo-staged kernel (conv_halo64.hip) instead of the gather kernel's 128x128 tile
     Halo64Args q;
@@ -190,7 +190,7 @@ extern "C" int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w
     q.H = d->H;
     q.W = d->W;
     q.CinP = r8(d->Cin);
-    q.cout_full = 128;
+    q.cout_full = d->Cout;
     q.mirror = 0;
     q.act = e->act;
     q.slope = e->slope;
@@ -776,9 +776,9 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
     // (named like the symbols of a rocprof summary: <mode 0> statistics epilogue, <1> plain, <2> folded inference epilogue)
     if (((is_c64(d) && !ps) || is_c64_wide(d)) && !nchw)
       return (e && (e->bn_scale || e->residual)) ? "conv_c64_kernel<2>" : (stats ? "conv_c64_kernel<0>" : "conv_c64_kernel<1>");
-    if (!ps && !nchw && !stats && !(e && (e->bn_scale || e->residual)) && d->Cout == 128 &&
+    if (!ps && !nchw && !stats && !(e && (e->bn_scale || e->residual)) && d->Cout % 64 == 0 && d->Cout >= 128 &&
         (!e || e->act == DSR_ACT_NONE || e->act == DSR_ACT_RELU || e->act == DSR_ACT_LEAKY) &&
-        dsr_halo64_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->H, d->W, r8(d->Cin), 128))
+        dsr_halo64_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->H, d->W, r8(d->Cin), d->Cout))
       return "conv_halo64_kernel";
     if (is_cin8(d, e)) return "conv_cin8_kernel";
     if (d->Cout <= 16 && d->stride == 1 && d->pad_mode == DSR_PAD_ZERO && d->KH * d->KW >= 9 && !stats && !ps &&
