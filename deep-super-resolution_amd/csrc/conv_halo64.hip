@@ -247,9 +247,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo64_kernel(const Halo64Args a)
 bool dsr_halo64_supported(int KH, int KW, int stride, int pad, int pad_mode, int H, int W, int CinP, int CoutP) {
   const char* e = getenv("DSR_CONV_HALO64");         // 0 = these layers stay on the gather kernel (read per call: a test compares the two)
   const bool on = !(e && e[0] == '0');
-  // (CoutP == 128: two 64-channel slices per spatial tile, DSR_CONV_HALO64=1 keeps those on the gather kernel; =3 / =4 (probes)
-  //  admit 256 / 512 outputs as four / eight slices)
-  const int max_out = (e && e[0] == '1') ? 64 : ((e && e[0] == '3') ? 256 : ((e && e[0] == '4') ? 512 : 128));
+  // (more than 64 outputs = several 64-channel slices per spatial tile: opt-in, DSR_CONV_HALO64=2 / 3 / 4 admit 128 / 256 / 512
+  //  outputs.  Measured: 128 outputs are 7-17 % faster than the gather kernel's 128x128 tile launch by launch (VGG conv2_2 0.77 ->
+  //  0.72 ms, D.b3's input gradient 0.33 -> 0.27) and the two-stream step 0.27 ms SLOWER with them (34.90 / 34.67 against 34.62 /
+  //  34.41 ms, same box, alternating) -- a persistent block that fills a CU's LDS leaves the other stream's kernels nothing to
+  //  run beside; 256 outputs are slower already launch by launch (0.63 vs 0.57 ms).  DESIGN.md 8.23)
+  const int max_out = (e && e[0] == '2') ? 128 : ((e && e[0] == '3') ? 256 : ((e && e[0] == '4') ? 512 : 64));
   const bool two = CoutP % 64 == 0 && CoutP > 64 && CoutP <= max_out;
   return on && KH == 3 && KW == 3 && stride == 1 && pad == 1 && pad_mode == DSR_PAD_ZERO && (CoutP == 64 || two) && CinP % 32 == 0 &&
          CinP >= 128 && CinP <= 1024 && H >= 8 && W >= 32 && (size_t)H * W * CinP * 2 < 0x7FFFFF00ull &&

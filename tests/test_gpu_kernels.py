@@ -977,8 +977,8 @@ def test_conv_halo64_dgrad_vs_gather_kernel_and_fp32(dev, n, h, w, cout):
 def test_conv_halo64_two_slices_of_64_outputs(dev, n, h, w, cin, cout):
     """conv_halo64_kernel on a layer with 128 outputs (forward: VGG conv2_2, utils/GAN.py:26, with bias + ReLU in the epilogue)
     or 128 inputs (input gradient, plain and with the ReLU mask of the activation in front folded into its stores): two
-    64-channel slices per spatial tile.  Against the gather kernel (DSR_CONV_HALO64=1 keeps 128-channel results there: the same
-    products in another order) and float64 conv2d / conv_transpose2d on the same bf16 operands.  Ragged tiles, K = 128 and 256,
+    64-channel slices per spatial tile (opt-in, DSR_CONV_HALO64=2: faster launch by launch, slower inside the two-stream step).
+    Against the gather kernel (the default for these layers: the same products in another order) and float64 conv2d / conv_transpose2d on the same bf16 operands.  Ragged tiles, K = 128 and 256,
     more (tile, slice) pairs than persistent blocks."""
     import ctypes as C
     import os
