@@ -486,13 +486,17 @@ __device__ __forceinline__ void st16(unsigned short* p, const U4& v) {
 }
 #define DSR_PW_NT_BYTES (192ull << 20)   // operand tensors of at least this size use the nontemporal path
 
-template <int DT, bool NT>
+// ACTC (this and the three kernels below): the activation as a compile-time constant (-1: the run-time `act`).  With the run-time
+// value every element went through act_apply's / act_grad_from_out's chain of scalar compares and branches (114-589 s_cbranch
+// per kernel): the launchers pick the instantiation for None / LeakyReLU / PReLU / ReLU.
+template <int DT, bool NT, int ACTC = -1>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const unsigned short* __restrict__ y,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          const unsigned short* __restrict__ residual,
-                                                         unsigned short* __restrict__ out, size_t P, int Cp, int act,
+                                                         unsigned short* __restrict__ out, size_t P, int Cp, int act_rt,
                                                          float slope_v, const float* __restrict__ prelu) {
+  const int act = ACTC >= 0 ? ACTC : act_rt;
   const int cpr = Cp / 8;
   const int rpi = 256 / cpr;
   const int ch = threadIdx.x % cpr, rr = threadIdx.x / cpr;
@@ -545,11 +549,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const unsigned short* _
 // pass 1: per-channel partial sums of g, g*xhat and the PReLU slope gradient sum(dout * z * [z<0]).
 // WITH_P: the launch also forms the PReLU slope gradient (8 more accumulators).  The per-channel scale / shift live in LDS (read
 // per row pair) rather than in 16 registers: with both, the two-rows-in-flight form fits 5 waves per SIMD instead of 4.
-template <int DT, bool NT, int UNR, bool WITH_P>
+template <int DT, bool NT, int UNR, bool WITH_P, int ACTC = -1>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     const unsigned short* __restrict__ dout, const unsigned short* __restrict__ y, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd, size_t P, int Cp,
-    int rows_per_block, int act, float slope_v, const float* __restrict__ prelu, float* __restrict__ partial) {
+    int rows_per_block, int act_rt, float slope_v, const float* __restrict__ prelu, float* __restrict__ partial) {
+  const int act = ACTC >= 0 ? ACTC : act_rt;
   __shared__ float red[256 * 24];
   const int cpr = Cp / 8;
   const int tid = threadIdx.x;
@@ -678,12 +683,13 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int bl
 
 // pass 2: dy = scale * (g - c1 - xhat * c2)      (scale = gamma * rstd), folded per channel into
 //   dy = A*g + B*y + C,  A = scale, B = -scale*c2*rstd, C = scale*(c2*mean*rstd - c1);  eval mode: dy = scale*g.
-template <int DT, bool NT>
+template <int DT, bool NT, int ACTC = -1>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const unsigned short* __restrict__ dout, const unsigned short* __restrict__ y, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ c1, const float* __restrict__ c2, unsigned short* __restrict__ dy, size_t P, int Cp,
-    int act, float slope_v, const float* __restrict__ prelu, int train) {
+    int act_rt, float slope_v, const float* __restrict__ prelu, int train) {
+  const int act = ACTC >= 0 ? ACTC : act_rt;
   const int cpr = Cp / 8;
   const int rpi = 256 / cpr;
   const int ch = threadIdx.x % cpr, rr = threadIdx.x / cpr;
@@ -740,13 +746,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
 // dy[conv layout] = dout * act'(out), where out is the stored activation OUTPUT (valid for slope > 0).
 // pixshuf: out/dout are [N][2H][2W][Cq] and dy is [N][H][W][4*C] with channel 4c+2i+j <- pixel (2h+i,2w+j).
 // Also emits per-block partial rows: [blocks][2][CyP] = (bias grad column sums, PReLU-slope grad terms).
-template <int DT, bool NT>
+template <int DT, bool NT, int ACTC = -1>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const unsigned short* __restrict__ dout,
                                                       const unsigned short* __restrict__ out,
                                                       unsigned short* __restrict__ dy, int N, int H, int W, int CyP,
-                                                      int CoP, int pixshuf, int act, float slope_v,
+                                                      int CoP, int pixshuf, int act_rt, float slope_v,
                                                       const float* __restrict__ prelu, int rows_per_block,
                                                       float* __restrict__ partial) {
+  const int act = ACTC >= 0 ? ACTC : act_rt;
   __shared__ float red[256 * 16];
   const int cpr = CyP / 8;
   const int tid = threadIdx.x;
@@ -1059,6 +1066,31 @@ __global__ void incr_kernel(int* step) { *step += 1; }
     CALL;                                      \
   }
 
+// the activation as a template constant for the pointwise BatchNorm / activation kernels (AC; -1 = run-time value)
+#define ACT_SWITCH(act, CALL)                  \
+  switch (act) {                               \
+    case DSR_ACT_NONE: {                       \
+      constexpr int AC = DSR_ACT_NONE;         \
+      CALL;                                    \
+    } break;                                   \
+    case DSR_ACT_LEAKY: {                      \
+      constexpr int AC = DSR_ACT_LEAKY;        \
+      CALL;                                    \
+    } break;                                   \
+    case DSR_ACT_PRELU: {                      \
+      constexpr int AC = DSR_ACT_PRELU;        \
+      CALL;                                    \
+    } break;                                   \
+    case DSR_ACT_RELU: {                       \
+      constexpr int AC = DSR_ACT_RELU;         \
+      CALL;                                    \
+    } break;                                   \
+    default: {                                 \
+      constexpr int AC = -1;                   \
+      CALL;                                    \
+    }                                          \
+  }
+
 static inline unsigned nblk(size_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 extern "C" int dsr_pw_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int Cp, hipStream_t st) {
@@ -1165,13 +1197,13 @@ extern "C" int dsr_pw_bn_act_fwd(int dtype, const void* y, const float* scale, c
   const bool nt = pw_nontemporal(P, Cp);
   const unsigned blocks = pw_grid(P, rpi, nt);
   if (nt) {
-    DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<DT, true>), dim3(blocks), dim3(256), 0, st,
+    ACT_SWITCH(act, DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<DT, true, AC>), dim3(blocks), dim3(256), 0, st,
                                         (const unsigned short*)y, scale, shift, (const unsigned short*)residual,
-                                        (unsigned short*)out, P, Cp, act, slope, prelu));
+                                        (unsigned short*)out, P, Cp, act, slope, prelu)));
   } else {
-    DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<DT, false>), dim3(blocks), dim3(256), 0, st,
+    ACT_SWITCH(act, DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<DT, false, AC>), dim3(blocks), dim3(256), 0, st,
                                         (const unsigned short*)y, scale, shift, (const unsigned short*)residual,
-                                        (unsigned short*)out, P, Cp, act, slope, prelu));
+                                        (unsigned short*)out, P, Cp, act, slope, prelu)));
   }
   return dsr_launch_status("dsr_pw_bn_act_fwd");
 }
@@ -1182,9 +1214,9 @@ extern "C" int dsr_pw_bn_act_bwd_reduce(int dtype, const void* dout, const void*
   DSR_REQUIRE(act != DSR_ACT_PRELU || prelu, "bn_act_bwd_reduce: PReLU needs its weight pointer");
   static const int unr = [] { const char* e = getenv("DSR_PW_REDUCE_UNROLL"); return e ? atoi(e) : 2; }();
 #define LAUNCH_RED2(NTV, U, WP)                                                                                             \
-  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DT, NTV, U, WP>), dim3(blocks), dim3(256), 0, st,           \
+  ACT_SWITCH(act, DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DT, NTV, U, WP, AC>), dim3(blocks), dim3(256), 0, st,           \
                                       (const unsigned short*)dout, (const unsigned short*)y, scale, shift, mean, rstd, P, \
-                                      Cp, rpb, act, slope, prelu, partial))
+                                      Cp, rpb, act, slope, prelu, partial)))
 #define LAUNCH_RED(NTV, U)                              \
   do {                                                  \
     if (act == DSR_ACT_PRELU) { LAUNCH_RED2(NTV, U, true); } else { LAUNCH_RED2(NTV, U, false); } \
@@ -1221,13 +1253,13 @@ extern "C" int dsr_pw_bn_act_bwd_apply(int dtype, const void* dout, const void* 
   const bool nt = pw_nontemporal(P, Cp);
   const unsigned blocks = pw_grid(P, rpi, nt);
   if (nt) {
-    DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DT, true>), dim3(blocks), dim3(256), 0, st,
+    ACT_SWITCH(act, DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DT, true, AC>), dim3(blocks), dim3(256), 0, st,
                                         (const unsigned short*)dout, (const unsigned short*)y, scale, shift, mean, rstd, c1,
-                                        c2, (unsigned short*)dy, P, Cp, act, slope, prelu, train));
+                                        c2, (unsigned short*)dy, P, Cp, act, slope, prelu, train)));
   } else {
-    DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DT, false>), dim3(blocks), dim3(256), 0, st,
+    ACT_SWITCH(act, DT_SWITCH(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DT, false, AC>), dim3(blocks), dim3(256), 0, st,
                                         (const unsigned short*)dout, (const unsigned short*)y, scale, shift, mean, rstd, c1,
-                                        c2, (unsigned short*)dy, P, Cp, act, slope, prelu, train));
+                                        c2, (unsigned short*)dy, P, Cp, act, slope, prelu, train)));
   }
   return dsr_launch_status("dsr_pw_bn_act_bwd_apply");
 }
@@ -1239,13 +1271,13 @@ extern "C" int dsr_pw_act_bwd(int dtype, const void* dout, const void* out, void
   // the derivative is taken from the stored OUTPUT, which identifies the branch only for a positive slope
   DSR_REQUIRE(act != DSR_ACT_LEAKY || slope > 0.f, "act_bwd: LeakyReLU slope %g must be > 0 (the activation gradient is derived from the stored output)", (double)slope);
   if (pw_nontemporal((size_t)N * H * W, CyP)) {
-    DT_SWITCH(dtype, hipLaunchKernelGGL((act_bwd_kernel<DT, true>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dout,
+    ACT_SWITCH(act, DT_SWITCH(dtype, hipLaunchKernelGGL((act_bwd_kernel<DT, true, AC>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dout,
                                         (const unsigned short*)out, (unsigned short*)dy, N, H, W, CyP, CoP, pixshuf, act,
-                                        slope, prelu, rpb, partial));
+                                        slope, prelu, rpb, partial)));
   } else {
-    DT_SWITCH(dtype, hipLaunchKernelGGL((act_bwd_kernel<DT, false>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dout,
+    ACT_SWITCH(act, DT_SWITCH(dtype, hipLaunchKernelGGL((act_bwd_kernel<DT, false, AC>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dout,
                                         (const unsigned short*)out, (unsigned short*)dy, N, H, W, CyP, CoP, pixshuf, act,
-                                        slope, prelu, rpb, partial));
+                                        slope, prelu, rpb, partial)));
   }
   return dsr_launch_status("dsr_pw_act_bwd");
 }
