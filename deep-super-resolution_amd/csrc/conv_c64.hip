@@ -474,7 +474,8 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const C64Args a) {
         }
         if constexpr (MODE == 3) {
           if (a.flags & DSR_F_MASK) {           // (uniform) the prefetched tile is an activation output: y = conv * act'(o)
-            v = act_mask8<DT>(v, rres[it], a.mask_act, a.mask_slope);
+            v = a.mask_act == DSR_ACT_RELU ? act_mask8<DT>(v, rres[it], DSR_ACT_RELU, 0.f)      // (constants per branch: no compare chain per element)
+                                           : act_mask8<DT>(v, rres[it], a.mask_act == DSR_ACT_NONE ? DSR_ACT_NONE : DSR_ACT_LEAKY, a.mask_slope);
           } else {
             float f[8], rr[8];
             unpack8<DT>(v, f);

@@ -657,14 +657,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NSTAGE == 3 || BM * BN >= 224 * 25
       const unsigned char* src = sC + (tid / CH) * C_STRIDE + (tid % CH) * 16;
       if (a.mask_x) {       // (uniform) dgrad with the upstream activation's backward mask folded into the stores
         const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.mask_x), 0, (unsigned)((size_t)a.M * a.CoutP * 2), 0x00020000);
+        // (the mask's activation as a constant per branch: with the run-time value every element went through
+        //  act_grad_from_out's chain of compares)
+        auto masked_stores = [&](auto maskf) {
 #pragma unroll
-        for (int it = 0; it < (BM * CH) / NT; ++it) {
-          const U4 v = *reinterpret_cast<const U4*>(src + it * (NT / CH) * C_STRIDE);
-          const U4 o = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(mr, sorg + lpart + it * step, 0, 0));
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned,
-                                                                    act_mask8<DT>(v, o, a.mask_act, a.mask_slope)),
-                                                 yr, sorg + lpart + it * step, 0, 0);
-        }
+          for (int it = 0; it < (BM * CH) / NT; ++it) {
+            const U4 v = *reinterpret_cast<const U4*>(src + it * (NT / CH) * C_STRIDE);
+            const U4 o = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(mr, sorg + lpart + it * step, 0, 0));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, maskf(v, o)), yr,
+                                                   sorg + lpart + it * step, 0, 0);
+          }
+        };
+        if (a.mask_act == DSR_ACT_RELU)
+          masked_stores([](const U4& v, const U4& o) { return act_mask8<DT>(v, o, DSR_ACT_RELU, 0.f); });
+        else if (a.mask_act == DSR_ACT_LEAKY || a.mask_act == DSR_ACT_PRELU)
+          masked_stores([&](const U4& v, const U4& o) { return act_mask8<DT>(v, o, DSR_ACT_LEAKY, a.mask_slope); });
+        else
+          masked_stores([&](const U4& v, const U4& o) { return act_mask8<DT>(v, o, a.mask_act, a.mask_slope); });
         return;
       }
 #pragma unroll

@@ -203,6 +203,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo64_kernel(const Halo64Args a)
     const int oy0 = cur.ty * H64_TR, ox0 = cur.tx * H64_TC;
     const unsigned sorg = (unsigned)(((cur.n * a.H + oy0) * a.W + ox0) * y_pix + cur.sl * 128);
     const bool full = oy0 + H64_TR <= a.H && ox0 + H64_TC <= a.W;
+    // (the activation and the mask's activation enter as callables chosen by wave-uniform branches OUTSIDE the store loops: with
+    //  the run-time values inside, every element went through act_apply's / act_grad_from_out's select chains)
+    auto epilogue = [&](auto actf, auto maskf) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       __builtin_amdgcn_s_barrier();          // every wave is done reading the stage (half 0) / the staged half (half 1)
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo64_kernel(const Halo64Args a)
         for (int nt = 0; nt < 2; ++nt) {
           float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = act_apply(a.act, acc[i][nt][r], slope);
+          for (int r = 0; r < 4; ++r) v[r] = actf(acc[i][nt][r]);
           uint2 pk;
           pk.x = (unsigned)f2h<DT>(v[0]) | ((unsigned)f2h<DT>(v[1]) << 16);
           pk.y = (unsigned)f2h<DT>(v[2]) | ((unsigned)f2h<DT>(v[3]) << 16);
@@ -234,12 +237,29 @@ __global__ __launch_bounds__(512, 2) void conv_halo64_kernel(const Halo64Args a)
                               // this gradient is taken with respect to (same shape as y) -- as conv_gemm.hip's masked stores
           const U4 o = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, off, 0, 0));
           __builtin_amdgcn_raw_buffer_store_b128(
-              __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, act_mask8<DT>(v, o, a.mask_act, a.mask_slope)), yrsrc, off, 0, 0);
+              __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, maskf(v, o)), yrsrc, off, 0, 0);
           continue;
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), yrsrc, off, 0, 0);
       }
     }
+    };
+    auto with_mask = [&](auto actf) {
+      if (a.mask_act == DSR_ACT_RELU)
+        epilogue(actf, [](const U4& v, const U4& o) { return act_mask8<DT>(v, o, DSR_ACT_RELU, 0.f); });
+      else if (a.mask_act == DSR_ACT_LEAKY || a.mask_act == DSR_ACT_PRELU)
+        epilogue(actf, [&](const U4& v, const U4& o) { return act_mask8<DT>(v, o, DSR_ACT_LEAKY, a.mask_slope); });
+      else
+        epilogue(actf, [&](const U4& v, const U4& o) { return act_mask8<DT>(v, o, a.mask_act, a.mask_slope); });
+    };
+    if (a.act == DSR_ACT_NONE)
+      with_mask([](float x) { return x; });
+    else if (a.act == DSR_ACT_RELU)
+      with_mask([](float x) { return x > 0.f ? x : 0.f; });
+    else if (a.act == DSR_ACT_LEAKY)
+      with_mask([slope](float x) { return x >= 0.f ? x : x * slope; });
+    else
+      with_mask([&](float x) { return act_apply(a.act, x, slope); });
     cur = nxt;
   }
 }
