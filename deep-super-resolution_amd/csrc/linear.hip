@@ -224,48 +224,59 @@ __global__ __launch_bounds__(512) void linear_fwd_kernel(const unsigned short* _
   f32x4 acc[MT][2];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  U4 vw[4], vx;
+  // KT 64-wide k tiles are requested together (a 256-byte run per weight row instead of 128-byte ones a step apart: the
+  // rows are K * 2 bytes = 1 MB apart, so every request opens a DRAM page of its own) and consumed one after the other
+  // through the same LDS tile.
+  constexpr int KT = 2;                      // k tiles requested together (4: slower again, 292 vs 252 us -- registers)
+  U4 vw[KT][4], vx[KT];
   auto gload = [&](size_t k) {
-    const size_t kk = k + lc * 8;
-    const bool kok = kk < k1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int o = ob + lr + 64 * i;
-      vw[i] = load16_or_zero(w, (size_t)o * K + kk, kok && o < O);
+    for (int h = 0; h < KT; ++h) {
+      const size_t kk = k + 64 * h + lc * 8;
+      const bool kok = kk < k1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = ob + lr + 64 * i;
+        vw[h][i] = load16_or_zero(w, (size_t)o * K + kk, kok && o < O);
+      }
+      vx[h] = load16_or_zero(x, (size_t)lr * K + kk, kok && lr < B);
     }
-    vx = load16_or_zero(x, (size_t)lr * K + kk, kok && lr < B);
   };
   gload(k0);
-  for (size_t k = k0; k < k1; k += 64) {
+  for (size_t k = k0; k < k1; k += 64 * KT) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = lr + 64 * i;
-      *reinterpret_cast<U4*>(sW + row * 128 + ((lc ^ (row & 7)) << 4)) = vw[i];
+    for (int h = 0; h < KT; ++h) {
+      if (k + 64 * h >= k1) break;                           // (uniform)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = lr + 64 * i;
+        *reinterpret_cast<U4*>(sW + row * 128 + ((lc ^ (row & 7)) << 4)) = vw[h][i];
+      }
+      *reinterpret_cast<U4*>(sX + lr * 128 + ((lc ^ (lr & 7)) << 4)) = vx[h];
+      __syncthreads();
+      if (h == KT - 1 && k + 64 * KT < k1) gload(k + 64 * KT);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ch = 4 * ks + g;
+        U4 fb[2], fa[MT];
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          const int row = wave * 32 + nf * 16 + r;
+          fb[nf] = *reinterpret_cast<const U4*>(sW + row * 128 + ((ch ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int row = 16 * m + r;
+          fa[m] = *reinterpret_cast<const U4*>(sX + row * 128 + ((ch ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          acc[m][0] = mfma16<DT>(fa[m], fb[0], acc[m][0]);
+          acc[m][1] = mfma16<DT>(fa[m], fb[1], acc[m][1]);
+        }
+      }
+      __syncthreads();
     }
-    *reinterpret_cast<U4*>(sX + lr * 128 + ((lc ^ (lr & 7)) << 4)) = vx;
-    __syncthreads();
-    if (k + 64 < k1) gload(k + 64);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ch = 4 * ks + g;
-      U4 fb[2], fa[MT];
-#pragma unroll
-      for (int nf = 0; nf < 2; ++nf) {
-        const int row = wave * 32 + nf * 16 + r;
-        fb[nf] = *reinterpret_cast<const U4*>(sW + row * 128 + ((ch ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int row = 16 * m + r;
-        fa[m] = *reinterpret_cast<const U4*>(sX + row * 128 + ((ch ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        acc[m][0] = mfma16<DT>(fa[m], fb[0], acc[m][0]);
-        acc[m][1] = mfma16<DT>(fa[m], fb[1], acc[m][1]);
-      }
-    }
-    __syncthreads();
   }
   float* P = partial + (size_t)blockIdx.y * B * O;
 #pragma unroll
