@@ -320,34 +320,44 @@ __device__ __forceinline__ s16x4 lds_tr_read16(const unsigned char* p) {
 // land in the other buffer afterwards: one barrier per stage, loads always in flight.
 // k-slot mapping of one 32-row stage (fixed by the transposing read): slots 0-3 of lane group g <-> rows 4g..4g+3,
 // slots 4-7 <-> rows 16+4g..16+4g+3.
-template <int DT, int MT>
+// NFW n-fragments per wave: 2 = 128 k columns per block (256-byte runs per weight row), 4 = 256 columns (512-byte runs: the rows
+// are 1 MB apart, every run opens a DRAM page of its own).
+template <int DT, int MT, int NFW = 2>
 __global__ __launch_bounds__(256) void linear_dgrad_kernel(const unsigned short* __restrict__ dy,
                                                            const unsigned short* __restrict__ w,
                                                            unsigned short* __restrict__ dx, int B, int O, size_t K) {
-  constexpr int WB = 32 * 256, YB = 64 * 80;
+  constexpr int COLS = 64 * NFW, RP = COLS * 2;            // k columns per block, bytes per staged weight row
+  constexpr int CPR = RP / 16, RPP = 256 / CPR, NLD = 32 / RPP;   // 16-byte chunks per row, rows per loader pass, passes per stage
+  constexpr int WB = 32 * RP, YB = 64 * 80;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (WB + YB)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, g = lane >> 4;
-  const size_t kb = (size_t)blockIdx.x * 128;
-  const int c = tid & 15, rr = tid >> 4;        // W loader: 16-byte chunk c of rows rr and rr+16
+  const size_t kb = (size_t)blockIdx.x * COLS;
+  const int c = tid % CPR, rr = tid / CPR;      // W loader: 16-byte chunk c of rows rr, rr + RPP, ...
   const bool kok = (kb + c * 8) < K;
   const int yb = tid >> 2, yc = tid & 3;        // dy loader: batch row yb, chunk yc (8 outputs)
   const bool ybok = yb < B;
-  f32x4 acc[MT][2];
+  f32x4 acc[MT][NFW];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int nf = 0; nf < NFW; ++nf) acc[m][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int q = l16 >> 2, cc = 4 * (l16 & 3);
-  U4 v0, v1, vy;
+  U4 vw[NLD], vy;
   auto gload = [&](int o0) {
-    v0 = load16_or_zero(w, (size_t)(o0 + rr) * K + kb + c * 8, kok && (o0 + rr) < O);
-    v1 = load16_or_zero(w, (size_t)(o0 + rr + 16) * K + kb + c * 8, kok && (o0 + rr + 16) < O);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      vw[i] = load16_or_zero(w, (size_t)(o0 + rr + RPP * i) * K + kb + c * 8, kok && (o0 + rr + RPP * i) < O);
     vy = load16_or_zero(dy, (size_t)yb * O + o0 + yc * 8, ybok && (o0 + yc * 8) < O);
   };
   auto sstore = [&](int buf) {
     unsigned char* sW = smem + buf * (WB + YB);
     unsigned char* sY = sW + WB;
-    *reinterpret_cast<U4*>(sW + rr * 256 + ((c ^ (rr & 15)) << 4)) = v0;
-    *reinterpret_cast<U4*>(sW + (rr + 16) * 256 + ((c ^ ((rr + 16) & 15)) << 4)) = v1;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int row = rr + RPP * i;
+      *reinterpret_cast<U4*>(sW + row * RP + ((c ^ (row & 15)) << 4)) = vw[i];
+    }
     *reinterpret_cast<U4*>(sY + yb * 80 + yc * 16) = vy;
   };
   const int nstage = (O + 31) / 32;
@@ -359,14 +369,14 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const unsigned short*
     if (s + 1 < nstage) gload(32 * (s + 1));
     const unsigned char* sW = smem + buf * (WB + YB);
     const unsigned char* sY = sW + WB;
-    U4 fb[2];
+    U4 fb[NFW];
 #pragma unroll
-    for (int nf = 0; nf < 2; ++nf) {
-      const int col = wave * 32 + nf * 16 + cc;
+    for (int nf = 0; nf < NFW; ++nf) {
+      const int col = wave * 16 * NFW + nf * 16 + cc;
       const int chunk = col >> 3, within = (col & 7) * 2;
       const int p1 = 4 * g + q, p2 = p1 + 16;
-      s16x4 b1 = lds_tr_read16(sW + p1 * 256 + ((chunk ^ (p1 & 15)) << 4) + within);
-      s16x4 b2 = lds_tr_read16(sW + p2 * 256 + ((chunk ^ (p2 & 15)) << 4) + within);
+      s16x4 b1 = lds_tr_read16(sW + p1 * RP + ((chunk ^ (p1 & 15)) << 4) + within);
+      s16x4 b2 = lds_tr_read16(sW + p2 * RP + ((chunk ^ (p2 & 15)) << 4) + within);
       fb[nf] = __builtin_bit_cast(U4, __builtin_shufflevector(b1, b2, 0, 1, 2, 3, 4, 5, 6, 7));
     }
 #pragma unroll
@@ -375,8 +385,8 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const unsigned short*
       const uint2 a1 = *reinterpret_cast<const uint2*>(row + 8 * g);
       const uint2 a2 = *reinterpret_cast<const uint2*>(row + 32 + 8 * g);
       U4 fa = {a1.x, a1.y, a2.x, a2.y};
-      acc[m][0] = mfma16<DT>(fa, fb[0], acc[m][0]);
-      acc[m][1] = mfma16<DT>(fa, fb[1], acc[m][1]);
+#pragma unroll
+      for (int nf = 0; nf < NFW; ++nf) acc[m][nf] = mfma16<DT>(fa, fb[nf], acc[m][nf]);
     }
     if (s + 1 < nstage) sstore(buf ^ 1);
     __syncthreads();
@@ -384,8 +394,8 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const unsigned short*
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int nf = 0; nf < 2; ++nf) {
-      const size_t k = kb + wave * 32 + nf * 16 + l16;
+    for (int nf = 0; nf < NFW; ++nf) {
+      const size_t k = kb + wave * 16 * NFW + nf * 16 + l16;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int b = 16 * m + 4 * g + j;
@@ -758,11 +768,17 @@ extern "C" int dsr_linear_dgrad(int dtype, const void* dy16, const void* w16, vo
   DSR_REQUIRE(dy16 && w16 && dx && DSR_DTYPE_OK(dtype) && K > 0 && O > 0, "linear_dgrad: null pointer or bad shape");
   if (B < 1 || B > 64) return dsr_fail(DSR_E_UNSUPPORTED, "linear: batch %d outside 1..64", B);
   if (K % 8 || O % 8) return dsr_fail(DSR_E_ARG, "linear_dgrad: K %% 8 or O %% 8");
-  dim3 grid((unsigned)((K + 127) / 128)), block(256);
+  const char* ew = getenv("DSR_LINEAR_DGRAD_COLS");       // tuning switch, read per call: 128 | 256 k columns per block
+  const bool wide = ew && atoi(ew) == 256 && K >= 256 * 512;
+  dim3 grid((unsigned)((K + (wide ? 255 : 127)) / (wide ? 256 : 128))), block(256);
   const unsigned short* DY = (const unsigned short*)dy16;
   const unsigned short* W = (const unsigned short*)w16;
   unsigned short* DX = (unsigned short*)dx;
-#define LAUNCH_DG(DTV, MTV) hipLaunchKernelGGL((linear_dgrad_kernel<DTV, MTV>), grid, block, 0, st, DY, W, DX, B, O, K)
+#define LAUNCH_DG(DTV, MTV)                                                                                     \
+  do {                                                                                                          \
+    if (wide) hipLaunchKernelGGL((linear_dgrad_kernel<DTV, MTV, 4>), grid, block, 0, st, DY, W, DX, B, O, K);   \
+    else hipLaunchKernelGGL((linear_dgrad_kernel<DTV, MTV, 2>), grid, block, 0, st, DY, W, DX, B, O, K);        \
+  } while (0)
   if (dtype == DSR_BF16) {
     if (B <= 32) LAUNCH_DG(DSR_DTYPE_BF16, 2); else LAUNCH_DG(DSR_DTYPE_BF16, 4);
   } else {
