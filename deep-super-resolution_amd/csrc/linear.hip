@@ -838,7 +838,7 @@ extern "C" int dsr_linear_wgrad_adam(int dtype, const void* dyT16_all, const voi
   if (R < 1) return dsr_fail(DSR_E_ARG, "linear_wgrad_adam: R < 1");
   if (K % 64) return dsr_fail(DSR_E_UNSUPPORTED, "linear_wgrad_adam: K %% 64 (use dsr_linear_wgrad + dsr_pw_adam)");
   const char* e = getenv("DSR_WGRAD_ADAM_KPB");      // tuning switch: 256-wide k groups per block
-  const int kpb = e ? atoi(e) : 2;
+  const int kpb = e ? atoi(e) : 1;          // (1: 2.71 ms stand-alone and 0.1-0.15 ms per config-3 step better than 2; 4 worse)
   if (kpb < 1) return dsr_fail(DSR_E_ARG, "linear_wgrad_adam: DSR_WGRAD_ADAM_KPB < 1");
   const size_t kgroups = (K + 255) / 256;
   dim3 grid((unsigned)((kgroups + kpb - 1) / kpb), (O + 63) / 64), block(256);
