@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 SOURCES = ["conv_gemm.hip", "conv_gemm_persist.hip", "conv_wgrad.hip", "conv_wgrad_tile.hip", "conv_smalln.hip",
-           "conv_c64.hip", "conv_halo64.hip", "conv_cin8.hip", "conv_dgrad_s2.hip", "conv_first_bwd.hip", "conv_first2.hip", "conv_api.hip", "pointwise.hip", "linear.hip",
+           "conv_c64.hip", "conv_halo64.hip", "conv_cin8.hip", "conv_rgb9.hip", "conv_dgrad_s2.hip", "conv_first_bwd.hip", "conv_first2.hip", "conv_api.hip", "pointwise.hip", "linear.hip",
            "resample.hip", "metrics.hip", "data.hip"]
 SO = os.path.join(CSRC, "libdsr_hip.so")
 # -Werror=return-type: a C-ABI entry point that flows off its end without `return` is undefined behaviour (hipcc -O3

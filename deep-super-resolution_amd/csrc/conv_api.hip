@@ -63,6 +63,10 @@ static bool is_cin8(const dsr_conv_desc* d, const dsr_epilogue* e) {   // first 
   return d->Cin <= 8 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
          d->pad_mode == DSR_PAD_ZERO && !(e && (e->stats_partial || e->pixel_shuffle || e->out_nchw_f32));
 }
+static bool is_rgb9(const dsr_conv_desc* d, const dsr_epilogue* e) {   // the generator's head: RGB -> 64, 9x9 s1 p4 (generator.py:48)
+  return dsr_conv_rgb9_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->Cin, d->Cout) &&
+         !(e && (e->stats_partial || e->pixel_shuffle || e->out_nchw_f32 || e->bn_scale || e->residual));
+}
 static bool is_tail9(const dsr_conv_desc* d) {
   return d->KH == 9 && d->KW == 9 && d->stride == 1 && d->pad == 4 && d->pad_mode == DSR_PAD_ZERO && d->Cout <= 3 &&
          r8(d->Cin) == 64;
@@ -224,7 +228,7 @@ extern "C" int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w
     dsr_launch_conv_c64(c, d->N, d->dtype, s);
     return dsr_launch_status("dsr_conv_fwd(c64)");
   }
-  if (is_cin8(d, e)) {
+  if (is_cin8(d, e) || is_rgb9(d, e)) {
     Cin8Args c;
     memset(&c, 0, sizeof(c));
     c.x = x;
@@ -236,6 +240,10 @@ extern "C" int dsr_conv_fwd(const dsr_conv_desc* d, const void* x, const void* w
     c.W = d->W;
     c.act = e->act;
     c.slope = e->slope;
+    if (is_rgb9(d, e)) {
+      dsr_launch_conv_rgb9(c, d->N, d->dtype, s);
+      return dsr_launch_status("dsr_conv_fwd(rgb9)");
+    }
     dsr_launch_conv_cin8(c, d->N, d->dtype, s);
     return dsr_launch_status("dsr_conv_fwd(cin8)");
   }
@@ -781,6 +789,7 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
         dsr_halo64_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->H, d->W, r8(d->Cin), d->Cout))
       return "conv_halo64_kernel";
     if (is_cin8(d, e)) return "conv_cin8_kernel";
+    if (is_rgb9(d, e)) return "conv_rgb9_kernel";
     if (d->Cout <= 16 && d->stride == 1 && d->pad_mode == DSR_PAD_ZERO && d->KH * d->KW >= 9 && !stats && !ps &&
         d->KW == 9 && d->KH <= 9 && r8(d->Cin) == 64)
       return "conv_smalln_kernel";

@@ -222,6 +222,9 @@ struct Cin8Args {
   int nt_store;        // output beyond the Infinity Cache: nontemporal stores (set by the launcher)
 };
 void dsr_launch_conv_cin8(Cin8Args& a, int N, int dtype, hipStream_t st);
+// the generator's 9x9 RGB -> 64 head, one kernel row per MFMA k-step (conv_rgb9.hip); same arguments
+int dsr_conv_rgb9_supported(int KH, int KW, int stride, int pad, int pad_mode, int Cin, int Cout);
+void dsr_launch_conv_rgb9(Cin8Args& a, int N, int dtype, hipStream_t st);
 
 // input gradient of a 3x3 stride-2 pad-1 convolution in one launch (conv_dgrad_s2.hip)
 struct DgradS2Args {

@@ -77,6 +77,8 @@ CONV_CASES = [
     ("trunk3x3", 2, 64, 64, 12, 20, 3, 1, 1, 0, "none"),
     ("trunk3x3_tail", 1, 64, 64, 7, 9, 3, 1, 1, 0, "leaky"),
     ("head9x9", 2, 3, 64, 16, 16, 9, 1, 4, 0, "prelu"),
+    ("head9x9_ragged", 3, 3, 64, 37, 45, 9, 1, 4, 0, "prelu"),          # conv_rgb9_kernel: 5 x 2 tiles per image, ragged right and bottom
+    ("head9x9_gray", 1, 1, 64, 9, 33, 9, 1, 4, 0, "leaky"),              # ... one real input channel, a map smaller than the window's reach
     ("d_first", 2, 3, 64, 16, 24, 3, 1, 1, 0, "leaky"),
     ("d_first_ragged", 3, 3, 64, 37, 70, 3, 1, 1, 0, "leaky"),
     ("c64_wide_192", 2, 64, 192, 19, 45, 3, 1, 1, 0, "relu"),          # weights-in-registers kernel, 3 output slices
@@ -611,6 +613,61 @@ def test_conv_dgrad_with_batchnorm_backward_sums(dev, n, h, w, cin, cout, actn):
     assert float((rowsum[0] - sg_ref).abs().max()) < tol_g and float((rowsum[1] - sgy_ref).abs().max()) < tol_gy
     for a_, b_ in zip(*outs):                       # dgamma, dbeta, c1, c2: the two sets of partial rows through the same finalize
         assert float((a_ - b_).abs().max()) < 1e-4 * float(b_.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("n,h,w,dt", [(2, 40, 72, "bf16"), (1, 128, 128, "bf16"), (1, 19, 35, "f16")])
+def test_generator_head_9x9_one_kernel_row_per_k_step(dev, n, h, w, dt, monkeypatch):
+    """conv_rgb9_kernel -- generator.py:48, Conv2d(3, 64, 9, 1, 4) + PReLU, with the RGB halo packed to 3 channels in LDS so
+    that one kernel row (9 taps x 3 channels) is one MFMA k-step read by a 2-byte-aligned 16-byte LDS load -- against an fp64
+    conv2d on the same rounded operands (one output rounding) and against the gather kernel it replaces (DSR_CONV_RGB9=0:
+    81 taps of 8 stored channels).  The k slots 27..31 of a fragment lie over the pixels x + 5, x + 6 of the halo row, outside
+    the window: an Inf planted in the image must reach exactly the 9 x 9 outputs whose window holds it, no column further."""
+    import ctypes as C
+    L = P("_lib")
+    F = P("functional")
+    lib = L.lib()
+    tdt, code = (torch.bfloat16, L.BF16) if dt == "bf16" else (torch.float16, L.F16)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cpu").manual_seed(h * w)
+    x = (torch.rand(n, 3, h, w, generator=g)).to(tdt).float()
+    wt = ((torch.rand(64, 3, 9, 9, generator=g) - 0.5) * 0.2).to(tdt).float()
+    b = (torch.rand(64, generator=g) - 0.5) * 0.2
+    d = L.ConvDesc(code, n, h, w, 3, 64, 9, 9, 1, 4, 0)
+    wf = torch.empty(lib.dsr_conv_packed_elems(C.byref(d), 0), dtype=tdt, device=dev)
+    wd = torch.empty(max(lib.dsr_conv_packed_elems(C.byref(d), 1), 8), dtype=tdt, device=dev)
+    L.check(lib.dsr_conv_pack_weight(C.byref(d), wt.to(dev).data_ptr(), wf.data_ptr(), wd.data_ptr(), st))
+    bg, ag = b.to(dev), torch.tensor([0.25], device=dev)
+    ep = L.Epilogue(F.ACT_PRELU, 0.0, ag.data_ptr(), bg.data_ptr(), None, 0, None, None, None, None)
+
+    def run(xin, rgb9):
+        monkeypatch.setenv("DSR_CONV_RGB9", "1" if rgb9 else "0")
+        assert lib.dsr_conv_kernel_name(C.byref(d), 0, C.byref(ep)).decode().startswith("conv_rgb9" if rgb9 else "conv_gemm")
+        xg = torch.zeros(n, h, w, 8, dtype=tdt, device=dev)
+        xg[..., :3] = xin.permute(0, 2, 3, 1).to(tdt).to(dev)
+        y = torch.full((n, h, w, 64), float("nan"), dtype=tdt, device=dev)
+        L.check(lib.dsr_conv_fwd(C.byref(d), xg.data_ptr(), wf.data_ptr(), C.byref(ep), y.data_ptr(), st))
+        torch.cuda.synchronize()
+        return y.float().cpu().permute(0, 3, 1, 2)
+    y_new, y_old = run(x, True), run(x, False)
+    ref = TF.conv2d(x.double(), wt.double(), b.double(), padding=4)
+    ref = torch.where(ref >= 0, ref, 0.25 * ref)
+    ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    tol = ulp * ref.abs().clamp_min(0.05) + 2e-5 * 243           # one output rounding + fp32 accumulation of 243 products
+    assert torch.isfinite(y_new).all()
+    assert float(((y_new - ref).abs() / tol).max()) <= 1.0, float(((y_new - ref).abs() / tol).max())
+    assert float(((y_new - y_old).abs() / (2 * tol)).max()) <= 1.0
+    # an Inf at (iy, ix): outputs within 4 pixels of it are non-finite (Inf, or NaN where the weight is 0 or signs cancel),
+    # every other output is what it was
+    iy, ix = h // 2, min(w - 1, 37)
+    xi = x.clone()
+    xi[0, 1, iy, ix] = float("inf")
+    y_inf = run(xi, True)
+    hit = torch.zeros(n, 1, h, w, dtype=torch.bool)
+    hit[0, 0, max(0, iy - 4):iy + 5, max(0, ix - 4):ix + 5] = True
+    bad = ~torch.isfinite(y_inf)
+    assert not bool((bad & ~hit).any()), "a non-finite input reached an output whose window does not hold it"
+    assert bool(bad[0, :, iy, ix].any())
+    assert torch.equal(torch.where(hit, torch.zeros(()), y_inf), torch.where(hit, torch.zeros(()), y_new))
 
 
 @pytest.mark.parametrize("n,h,w,cin,actn", [(2, 6, 512, 3, "leaky"), (1, 4, 1024, 3, "relu"), (3, 2, 512, 1, "leaky"), (130, 4, 512, 3, "leaky")])
