@@ -67,6 +67,11 @@ static bool is_rgb9(const dsr_conv_desc* d, const dsr_epilogue* e) {   // the ge
   return dsr_conv_rgb9_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->Cin, d->Cout) &&
          !(e && (e->stats_partial || e->pixel_shuffle || e->out_nchw_f32 || e->bn_scale || e->residual));
 }
+// weight gradient of the generator's 9x9 RGB head on conv_rgb9_wgrad_kernel (DSR_CONV_RGB9=0: the tap-per-MFMA kernel)
+static bool is_rgb9_wgrad(const dsr_conv_desc* d) {
+  return dsr_conv_rgb9_supported(d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->Cin, d->Cout) != 0;
+}
+
 static bool is_tail9(const dsr_conv_desc* d) {
   return d->KH == 9 && d->KW == 9 && d->stride == 1 && d->pad == 4 && d->pad_mode == DSR_PAD_ZERO && d->Cout <= 3 &&
          r8(d->Cin) == 64;
@@ -580,6 +585,7 @@ static int tile_plan(const dsr_conv_desc* d, WgradTileArgs& t, bool* taps_kernel
 
 extern "C" size_t dsr_conv_wgrad_workspace(const dsr_conv_desc* d) {
   if (check_desc(d)) return 0;
+  if (is_rgb9_wgrad(d)) return (size_t)dsr_wgrad_rgb9_blocks(d->N, d->H, d->W) * dsr_wgrad_rgb9_slab_floats() * sizeof(float);
   WgradTileArgs t;
   int ych = tile_plan(d, t);
   if (ych > 0) return (size_t)(ych + DSR_WGRAD_SCRATCH_SLABS) * d->KH * d->KW * t.CoutP * t.CinP * sizeof(float);
@@ -596,6 +602,17 @@ extern "C" int dsr_conv_wgrad(const dsr_conv_desc* d, const void* x, const void*
   if (!x || !dy || !dw) return dsr_fail(DSR_E_ARG, "conv_wgrad: null pointer");
   size_t need = dsr_conv_wgrad_workspace(d);
   if (!workspace || ws_bytes < need) return dsr_fail(DSR_E_WORKSPACE, "conv_wgrad: workspace %zu < %zu", ws_bytes, need);
+  if (is_rgb9_wgrad(d)) {
+    Rgb9WgradArgs q;
+    memset(&q, 0, sizeof(q));
+    q.x = x;
+    q.dy = dy;
+    q.partial = (float*)workspace;
+    q.H = d->H;
+    q.W = d->W;
+    dsr_launch_wgrad_rgb9(q, d->N, d->Cin, dw, d->dtype, s);
+    return dsr_launch_status("dsr_conv_wgrad(rgb9)");
+  }
   WgradTileArgs t;
   bool taps_kernel = false, toeplitz = false;
   int ych = tile_plan(d, t, &taps_kernel, &toeplitz);
@@ -810,6 +827,7 @@ extern "C" const char* dsr_conv_kernel_name(const dsr_conv_desc* d, int op, cons
     const long long Mg = (long long)d->N * ((d->H + d->stride - 1) / d->stride) * ((d->W + d->stride - 1) / d->stride);
     return gemm_name(r8(d->Cin), Mg, r8(d->Cout) % 64 == 0 && (d->pad_mode == DSR_PAD_ZERO || d->pad == 0), false);
   }
+  if (is_rgb9_wgrad(d)) return "conv_rgb9_wgrad_kernel";
   WgradTileArgs t;
   bool taps = false;
   bool toep = false;

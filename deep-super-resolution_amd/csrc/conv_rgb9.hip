@@ -216,3 +216,200 @@ void dsr_launch_conv_rgb9(Cin8Args& a, int N, int dtype, hipStream_t st) {
   else
     hipLaunchKernelGGL((conv_rgb9_kernel<DSR_DTYPE_F16>), dim3(blocks), dim3(256), 0, st, a);
 }
+
+// ------------------------------------------------------------------ weight gradient of the same layer
+// dW[co][c][ky][kx] = sum_{n,y,x} dy[n][y][x][co] * img[n][y + ky - 4][x + kx - 4][c].  With the packed halo row the 27 products
+// of kernel row ky under pixel x read row[3x + k'], k' = 3 kx + c: per (output row y, ky) ONE GEMM over the 32 pixels of a tile
+// row,  D_ky[co][k'] += A[co][x] B[x][k'],  A = dy^T (transposing LDS reads of the staged dy tile), B[x][k'] = row_{y+ky}[3x + k']
+// -- 8 MFMAs (4 cout tiles x 2 k' tiles) per (row, ky) against 324 on the tap-per-MFMA kernel (81 taps x 4, 3 of 16 columns
+// used: 0.123 ms at config 3).  B through the same transposing read: a lane hands in the 8 bytes (pixel p, k' .. k' + 3) at
+// 6 p + 2 k', which must be 8-byte aligned: FOUR copies of the halo, copy r one element further right than copy r - 1, pixel p
+// reads copy p % 4.  The pixel order inside a k-step is the transposing read's (4g + j, 16 + 4g + j), the same for A and B.
+// Waves split the kernel rows (0: ky 0, 4, 8; w: ky w, w + 4), every wave reads all four A fragments of a tile row.
+// Each block leaves ONE partial slab [9][64][32] (k' = 27..31: unused columns); rgb9_wgrad_reduce_kernel sums the slabs.
+namespace {
+constexpr int WG_COPY = HROWS * ROW_BYTES;          // 4 KB per halo copy
+constexpr int WG_X = 4 * WG_COPY;                   // 16 KB
+constexpr int WG_Y = TH * TW * 128;                 // 32 KB: dy tile [pixel][64 cout], 16-byte chunks swizzled by pixel
+constexpr int WG_SLAB = KS * 64 * 32;               // floats per partial slab
+__device__ __forceinline__ s16x4 tr_read8(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+}   // namespace
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv_rgb9_wgrad_kernel(const Rgb9WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[WG_X + WG_Y];
+  unsigned char* sX = smem;
+  unsigned char* sY = smem + WG_X;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, c4 = l16 & 3;
+  const int nky = wave == 0 ? 3 : 2;                 // kernel rows wave, wave + 4 (, 8)
+
+  f32x4 acc[3][4][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[t][i][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // all four copies zeroed once: the bytes around a row's 40 pixels are never written again (they feed k' >= 27 only, but must
+  // not be NaN patterns next to real columns of the same MFMA: 0 * NaN)
+#pragma unroll
+  for (int i = 0; i < WG_X / (256 * 16); ++i) *reinterpret_cast<U4*>(sX + (tid + 256 * i) * 16) = U4{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  const int per_img = a.tiles_y * a.tiles_x;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  int hy[3], hx[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int hp = tid + 256 * i;
+    hy[i] = hp / HCOLS;
+    hx[i] = hp - hy[i] * HCOLS;
+  }
+  const bool has2 = tid + 512 < HALO;
+  typedef __attribute__((ext_vector_type(2))) unsigned U2;
+  U2 hv[3];
+  U4 yv[TH];                                         // this thread's 16-byte chunk (tid & 7) of pixel (tid >> 3) of every tile row
+  auto gload = [&](int tile) {
+    const int n = tile / per_img, rem = tile - n * per_img;
+    const int ty = rem / a.tiles_x;
+    const int oy0 = ty * TH, ox0 = (rem - ty * a.tiles_x) * TW;
+    const int nb = n * a.H * a.W;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int iy = oy0 - KS / 2 + hy[i], ix = ox0 - KS / 2 + hx[i];
+      const bool ok = (i < 2 || has2) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      hv[i] = __builtin_bit_cast(U2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, ok ? (unsigned)(nb + iy * a.W + ix) * 16u : OOB, 0, 0));
+    }
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+      const int oy = oy0 + r, ox = ox0 + (tid >> 3);
+      const bool ok = oy < a.H && ox < a.W;
+      yv[r] = __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(
+                                         yrsrc, ok ? (unsigned)((nb + oy * a.W + ox) * 128 + (tid & 7) * 16) : OOB, 0, 0));
+    }
+  };
+  // B fragment address of this lane inside a halo row: pixel 4g + q4 (its copy: q4), k' = 4 c4 .. + 3 (+ 16 nt, + 6 * 16 for hi)
+  const int boff = q4 * WG_COPY + 6 * (4 * g + q4) + 2 * q4 + 8 * c4;
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) gload(tile);
+  while (tile < a.ntiles) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < 2 || has2) {
+        unsigned short* d = reinterpret_cast<unsigned short*>(sX + hy[i] * ROW_BYTES + hx[i] * 6);
+        const unsigned short e0 = (unsigned short)hv[i].x, e1 = (unsigned short)(hv[i].x >> 16), e2 = (unsigned short)hv[i].y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          d[r * (WG_COPY / 2) + r] = e0;
+          d[r * (WG_COPY / 2) + r + 1] = e1;
+          d[r * (WG_COPY / 2) + r + 2] = e2;
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+      const int p = r * TW + (tid >> 3);
+      *reinterpret_cast<U4*>(sY + p * 128 + (((tid & 7) ^ (p & 7)) << 4)) = yv[r];
+    }
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < a.ntiles) gload(next);
+
+#pragma unroll 1
+    for (int r = 0; r < TH; ++r) {
+      U4 fa[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ch = i * 16 + 4 * c4;
+        const int p1 = r * TW + 4 * g + q4, p2 = p1 + 16;
+        const s16x4 lo = tr_read8(sY + p1 * 128 + (((ch >> 3) ^ (p1 & 7)) << 4) + (ch & 7) * 2);
+        const s16x4 hi = tr_read8(sY + p2 * 128 + (((ch >> 3) ^ (p2 & 7)) << 4) + (ch & 7) * 2);
+        fa[i] = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if (t < nky) {                               // wave-uniform
+          const int ky = wave + 4 * t;
+          const unsigned char* row = sX + (r + ky) * ROW_BYTES + boff;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const s16x4 lo = tr_read8(row + 32 * nt);
+            const s16x4 hi = tr_read8(row + 32 * nt + 96);
+            const U4 fb = __builtin_bit_cast(U4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[t][i][nt] = mfma16<DT>(fa[i], fb, acc[t][i][nt]);
+          }
+        }
+      }
+    }
+    __syncthreads();   // every wave is done with the tile before the next one overwrites it
+    tile = next;
+  }
+  float* P = a.partial + (size_t)blockIdx.x * WG_SLAB;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+    if (t < nky) {
+      const int ky = wave + 4 * t;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) P[(ky * 64 + 16 * i + 4 * g + r) * 32 + 16 * nt + l16] = acc[t][i][nt][r];
+    }
+}
+
+// dw[co][c][ky][kx] = sum over the slabs of P[ky][co][3 kx + c].  A block = 32 consecutive (ky, co, k') x 8 slab groups: group q
+// sums slabs q, q + 8, ... (8 loads in flight), the 8 group sums are added in group order through LDS -- fixed order, double:
+// deterministic.  (One thread per output walking all 256 slabs was a 64-deep load chain: 40 of the launch pair's 67 us.)
+__global__ __launch_bounds__(256) void rgb9_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int slabs,
+                                                                int Cin) {
+  __shared__ double red[8][32];
+  const int idx = blockIdx.x * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;     // (ky, co, k') ; slab group
+  double s = 0.0;
+  int z = q;
+  for (; z + 56 < slabs; z += 64) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(z + 8 * u) * WG_SLAB + idx];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (double)v[u];
+  }
+  for (; z < slabs; z += 8) s += (double)partial[(size_t)z * WG_SLAB + idx];
+  red[q][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (q != 0) return;
+#pragma unroll
+  for (int u = 1; u < 8; ++u) s += red[u][threadIdx.x];
+  const int kp = idx & 31, co = (idx >> 5) & 63, ky = idx >> 11;
+  const int kx = kp / 3, c = kp - 3 * kx;
+  if (kp >= 27 || c >= Cin) return;
+  dw[((size_t)co * Cin + c) * (KS * KS) + ky * KS + kx] = (float)s;
+}
+
+// blocks (= partial slabs of WG_SLAB floats) the launch will use
+int dsr_wgrad_rgb9_blocks(int N, int H, int W) {
+  const long long nt = (long long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  static const int cap = [] { const char* e = getenv("DSR_RGB9_WGRAD_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();   // tuning switch (measured at config 3: 256 blocks 47 us, 512 43, 1024 slower: the slabs)
+  return (int)(nt < cap ? nt : cap);                  // persistent, two blocks per CU: one slab per block, 4 tiles each at config 3
+}
+size_t dsr_wgrad_rgb9_slab_floats() { return WG_SLAB; }
+
+void dsr_launch_wgrad_rgb9(Rgb9WgradArgs& a, int N, int Cin, float* dw, int dtype, hipStream_t st) {
+  a.tiles_y = (a.H + TH - 1) / TH;
+  a.tiles_x = (a.W + TW - 1) / TW;
+  a.ntiles = N * a.tiles_y * a.tiles_x;
+  a.x_bytes = (unsigned)((size_t)N * a.H * a.W * 16);
+  a.dy_bytes = (unsigned)((size_t)N * a.H * a.W * 128);
+  const int blocks = dsr_wgrad_rgb9_blocks(N, a.H, a.W);
+  if (dtype == DSR_DTYPE_BF16)
+    hipLaunchKernelGGL((conv_rgb9_wgrad_kernel<DSR_DTYPE_BF16>), dim3(blocks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_rgb9_wgrad_kernel<DSR_DTYPE_F16>), dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(rgb9_wgrad_reduce_kernel, dim3(WG_SLAB / 32), dim3(256), 0, st, (const float*)a.partial, dw, blocks, Cin);
+}

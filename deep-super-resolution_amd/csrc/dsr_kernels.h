@@ -225,6 +225,17 @@ void dsr_launch_conv_cin8(Cin8Args& a, int N, int dtype, hipStream_t st);
 // the generator's 9x9 RGB -> 64 head, one kernel row per MFMA k-step (conv_rgb9.hip); same arguments
 int dsr_conv_rgb9_supported(int KH, int KW, int stride, int pad, int pad_mode, int Cin, int Cout);
 void dsr_launch_conv_rgb9(Cin8Args& a, int N, int dtype, hipStream_t st);
+struct Rgb9WgradArgs {
+  const void* x;       // [N][H][W][8]
+  const void* dy;      // [N][H][W][64]
+  float* partial;      // dsr_wgrad_rgb9_blocks() slabs of dsr_wgrad_rgb9_slab_floats() floats
+  int H, W;
+  int tiles_y, tiles_x, ntiles;      // filled by the launcher
+  unsigned x_bytes, dy_bytes;
+};
+int dsr_wgrad_rgb9_blocks(int N, int H, int W);
+size_t dsr_wgrad_rgb9_slab_floats();
+void dsr_launch_wgrad_rgb9(Rgb9WgradArgs& a, int N, int Cin, float* dw, int dtype, hipStream_t st);   // kernel + slab reduction -> dw [64][Cin][9][9]
 
 // input gradient of a 3x3 stride-2 pad-1 convolution in one launch (conv_dgrad_s2.hip)
 struct DgradS2Args {

@@ -656,6 +656,30 @@ def test_generator_head_9x9_one_kernel_row_per_k_step(dev, n, h, w, dt, monkeypa
     assert torch.isfinite(y_new).all()
     assert float(((y_new - ref).abs() / tol).max()) <= 1.0, float(((y_new - ref).abs() / tol).max())
     assert float(((y_new - y_old).abs() / (2 * tol)).max()) <= 1.0
+    # ---- weight gradient (conv_rgb9_wgrad_kernel: one GEMM per (tile row, kernel row) over the row's 32 pixels) against float64
+    # and against the tap-per-MFMA kernel it replaces
+    dy = ((torch.rand(n, 64, h, w, generator=g) - 0.5)).to(tdt).float()
+    dyg = dy.permute(0, 2, 3, 1).contiguous().to(tdt).to(dev)
+    xg8 = torch.zeros(n, h, w, 8, dtype=tdt, device=dev)
+    xg8[..., :3] = x.permute(0, 2, 3, 1).to(tdt).to(dev)
+
+    def wgrad(rgb9):
+        monkeypatch.setenv("DSR_CONV_RGB9", "1" if rgb9 else "0")
+        assert lib.dsr_conv_kernel_name(C.byref(d), 2, None).decode() == ("conv_rgb9_wgrad_kernel" if rgb9 else "conv_wgrad_taps_kernel")
+        wsz = lib.dsr_conv_wgrad_workspace(C.byref(d))
+        ws = torch.full((wsz // 4,), float("nan"), dtype=torch.float32, device=dev)
+        dw = torch.full((64, 3, 9, 9), float("nan"), dtype=torch.float32, device=dev)
+        L.check(lib.dsr_conv_wgrad(C.byref(d), xg8.data_ptr(), dyg.data_ptr(), dw.data_ptr(), ws.data_ptr(), wsz, st))
+        torch.cuda.synchronize()
+        return dw.cpu().double()
+    dw_new, dw_old = wgrad(True), wgrad(False)
+    xr = x.double().requires_grad_(True)
+    wr = wt.double().requires_grad_(True)
+    TF.conv2d(xr, wr, None, padding=4).backward(dy.double())
+    scale_w = float(wr.grad.abs().max())
+    assert torch.isfinite(dw_new).all()
+    assert float((dw_new - wr.grad).abs().max()) <= 2e-5 * scale_w * 8, float((dw_new - wr.grad).abs().max()) / scale_w
+    assert float((dw_new - dw_old).abs().max()) <= 4e-5 * scale_w * 8
     # an Inf at (iy, ix): outputs within 4 pixels of it are non-finite (Inf, or NaN where the weight is 0 or signs cancel),
     # every other output is what it was
     iy, ix = h // 2, min(w - 1, 37)
