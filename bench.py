@@ -15,7 +15,7 @@ The driver launches the ranks with torch.distributed.run; `python bench.py --gpu
 child process, before this process touches the GPU) and relays rank 0's JSON line.  Rank 0 prints ONE JSON line.
 
 Extra legs (rank 0, N = 1 only; each can be switched off):
-  roofline      : one more step, not timed for throughput, with EVERY kernel launch bracketed by HIP events on its launch
+  roofline      : three more steps, not timed for throughput, with EVERY kernel launch bracketed by HIP events on its launch
                   stream.  Convolution launches are grouped by the kernel the dispatcher selects; for the family with the
                   largest total time: achieved = sum of algorithmic FLOPs (2*N*OH*OW*Cout*KH*KW*Cin) / sum of durations,
                   against the dense bf16 MFMA peak (2.5 PFLOP/s).  Also: whole-step algorithmic FLOP/s over peak
@@ -387,16 +387,29 @@ def psnr_delta(workload, dev):
 
 
 def roofline(step, workload, ms_per_step):
-    """One eager step with every launch bracketed by HIP events on its launch stream (see module docstring)."""
+    """An eager step with every launch bracketed by HIP events on its launch stream (see module docstring)."""
     F, L = P("functional"), P("_lib")
     fn = getattr(step, "eager", step)
     fn()                                   # (eager warm-up: packed-weight caches, allocator)
     torch.cuda.synchronize()
-    F.KERNEL_LOG, L.LAUNCH_LOG = [], []
-    fn()
-    torch.cuda.synchronize()
-    conv_log, all_log = F.KERNEL_LOG, L.LAUNCH_LOG
+    # three bracketed steps: per kernel family the median of its three totals is reported (one step's two grouped
+    # weight-gradient launches alone read 1.64 .. 1.81 ms from run to run on this power-managed chip), busy time likewise
+    runs = []
+    for _ in range(3):
+        F.KERNEL_LOG, L.LAUNCH_LOG = [], []
+        # DSR_BENCH_SPIN=1 (probe): the host issues the step while the GPU spins, so that every bracket opens when the previous
+        # launch ends with its own launch already queued (no host time inside a bracket, the chip continuously loaded as in
+        # the replayed step).  Measured on one box against the rocprofv3 summary of the same command: the grouped weight
+        # gradient reads the same either way (3.22-3.34 ms per step, rocprof 3.34), the 14 launches of the 256x256 tile read
+        # 3.38-3.40 with the spin and 3.20-3.28 without (rocprof 3.12): off by default, the brackets closest to the trace.
+        if os.environ.get("DSR_BENCH_SPIN", "0") == "1":
+            torch.cuda._sleep(int(0.10 * 2.0e9))
+        fn()
+        torch.cuda.synchronize()
+        runs.append((sum(e0.elapsed_time(e1) for _, e0, e1 in L.LAUNCH_LOG), F.KERNEL_LOG, L.LAUNCH_LOG))
     F.KERNEL_LOG = L.LAUNCH_LOG = None
+    _, conv_log, all_log = sorted(runs, key=lambda r: r[0])[1]
+    med = lambda v: sorted(v)[len(v) // 2]
     # An event pair with nothing between its two records still reads a few microseconds (the markers themselves): measured
     # here and taken off every kernel bracket, so that the per-kernel averages agree with a rocprofv3 --kernel-trace summary
     # of the same command (profiles/r02_gan_x4_serial_kernel_stats.csv) instead of sitting ~8 % above it.
@@ -408,16 +421,20 @@ def roofline(step, workload, ms_per_step):
         empty.append((a0, a1))
     torch.cuda.synchronize()
     ev_ms = sorted(x.elapsed_time(y) for x, y in empty)[len(empty) // 2]
-    fam = {}
-    for kind, d, e0, e1, k in conv_log:
-        t, fl, cnt = fam.get(k, (0.0, 0.0, 0))
-        # one C-ABI call = one kernel launch, except a strided dgrad on the gather kernel (stride^2 parity classes)
-        nl = d[7] * d[7] if (kind == "dgrad" and k.startswith("conv_gemm")) else 1
-        flops = sum(conv_flops(q) for q in d) if kind == "wgrad_batch" else conv_flops(d)   # (a grouped launch: many layers)
-        fam[k] = (t + max(e0.elapsed_time(e1) - ev_ms, 0.0) * 1e-3, fl + flops, cnt + nl)
+    def families(log):
+        fam = {}
+        for kind, d, e0, e1, k in log:
+            t, fl, cnt = fam.get(k, (0.0, 0.0, 0))
+            # one C-ABI call = one kernel launch, except a strided dgrad on the gather kernel (stride^2 parity classes)
+            nl = d[7] * d[7] if (kind == "dgrad" and k.startswith("conv_gemm")) else 1
+            flops = sum(conv_flops(q) for q in d) if kind == "wgrad_batch" else conv_flops(d)   # (a grouped launch: many layers)
+            fam[k] = (t + max(e0.elapsed_time(e1) - ev_ms, 0.0) * 1e-3, fl + flops, cnt + nl)
+        return fam
+    fams = [families(r[1]) for r in runs]
+    fam = {k: (med([f[k][0] for f in fams if k in f]), v[1], v[2]) for k, v in families(conv_log).items()}
     if not fam:
         return None
-    busy = sum(e0.elapsed_time(e1) for _, e0, e1 in all_log)
+    busy = med([r[0] for r in runs])
     by_entry = {}
     for name, e0, e1 in all_log:
         by_entry[name] = by_entry.get(name, 0.0) + e0.elapsed_time(e1)
@@ -428,8 +445,9 @@ def roofline(step, workload, ms_per_step):
     return {"bound": "mfma", "kernel": top, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(workload, top),
             "launches": cnt, "avg_launch_ms": t / cnt * 1e3, "event_pair_overhead_ms": ev_ms,
-            "measured_on": "an eager single-stream run of the step (per-kernel HIP-event brackets are not stretched by a "
-                           "concurrent stream); the timed steps replay the same launches",
+            "measured_on": "three eager single-stream runs of the step, per kernel family the median of its three totals "
+                           "(per-kernel HIP-event brackets are not stretched by a concurrent stream); the timed steps "
+                           "replay the same launches",
             "step_algorithmic_tflops": step_tf, "step_frac": step_tf / MFMA_BF16_PEAK_TFLOPS,
             "gpu_busy_ms": busy, "launches_total": len(all_log),
             "launch_gap_share": max(0.0, 1.0 - busy / ms_per_step) if busy < ms_per_step else 0.0,
